@@ -1,0 +1,107 @@
+/*
+ * pycllp_hip.h -- C ABI of libpycllp_hip.so, the MI355X (gfx950) implementation of pycllp's batched
+ * dense primal-normal-equations interior-point path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every pointer argument
+ * named *_dev is a DEVICE pointer owned by the caller (the Python host passes torch tensors'
+ * data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point
+ * synchronises the host with the device except where stated; all of them are re-entrant per handle.
+ * Return value: 0 on success, a negative PYCLLP_E_* code for argument errors, or a positive
+ * hipError_t for runtime failures (pycllp_hip_last_error() gives the text).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   pycllp_hip_dense_init   <- ClDensePrimalNormalSolver.init      pycllp/solvers/cl.py:28-83
+ *                              (densify+upload A once, allocate per-solver device state)
+ *   pycllp_hip_dense_solve  <- ClDensePrimalNormalSolver.solve     pycllp/solvers/cl.py:85-124
+ *                              kernels initialize_xzyw              pycllp/cl/primal_normal.cl:14-28
+ *                                      standard_primal_normal       pycllp/cl/primal_normal.cl:201-284
+ *                                      (-> solve_primal_normal      pycllp/cl/ldl.cl:602-653,
+ *                                          primal_normal_step       pycllp/cl/primal_normal.cl:122-156)
+ *   pycllp_hip_dense_newton <- kernel solve_primal_normal launched stand-alone by the reference's
+ *                              tests/test_ldl.py:219-273            pycllp/cl/ldl.cl:602-653
+ *   pycllp_hip_dense_free   <- release of ClDensePrimalNormalSolver.buffers  pycllp/solvers/cl.py:26
+ *
+ * Layouts are the problem-major ones of the LP container (pycllp/lp.py:338-347), NOT the
+ * batch-interleaved transposes the OpenCL host builds (pycllp/solvers/cl.py:99,102):
+ *   A [m, n] row-major (shared by the batch);  b [B, m];  c [B, n];  x, z [B, n];  y [B, m].
+ * The LP is in equality form: maximise c'x subject to A x = b, x >= 0 (pycllp/lp.py:306-330).
+ */
+#ifndef PYCLLP_HIP_H
+#define PYCLLP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYCLLP_HIP_ABI_VERSION 1
+
+/* per-LP status codes, identical to the reference (pycllp/cl/primal_normal.cl:225,257,262,267;
+ * pycllp/solvers/normal_eqns.py:85-87; names in pycllp/common/main.c:21-30) */
+#define PYCLLP_STATUS_OPTIMAL 0
+#define PYCLLP_STATUS_PRIMAL_INFEASIBLE 2
+#define PYCLLP_STATUS_NUMERICAL 3
+#define PYCLLP_STATUS_DUAL_INFEASIBLE 4
+#define PYCLLP_STATUS_ITERATION_LIMIT 5
+
+#define PYCLLP_E_BADARG (-1)      /* NULL pointer / non-positive size                     */
+#define PYCLLP_E_UNSUPPORTED (-2) /* (m, n) outside what the compiled kernels cover        */
+#define PYCLLP_E_NOMEM (-3)
+
+/* flags */
+#define PYCLLP_FLAG_WARM_START 1 /* x, z, y are in/out: start from the caller's point instead of
+                                    x=z=y=1 (intent of pycllp/cl/primal_normal.cl:213-219)  */
+
+typedef struct pycllp_hip_opts {
+    double eps;         /* relative stopping tolerance on |rho|,|sigma|,gamma; default 1e-10.
+                           (reference: absolute EPS 1e-7f, primal_normal.cl:8,256)           */
+    double delta;       /* centering parameter DELTA, default 0.02 (primal_normal.cl:10)     */
+    double r;           /* step fraction R, default 0.9 (primal_normal.cl:11)                */
+    double pivot_floor; /* LDL' diagonal floor, default 1e-6 (primal_normal.cl:275)          */
+    double refine_tol;  /* refinement tolerance, default 1e-8 (ldl.cl:645)                   */
+    int max_iter;       /* default 200 (primal_normal.cl:9)                                  */
+    int max_refine;     /* default 5 (ldl.cl:645)                                            */
+    int flags;          /* PYCLLP_FLAG_*                                                     */
+    int reserved;
+} pycllp_hip_opts;
+
+typedef struct pycllp_hip_dense pycllp_hip_dense; /* opaque per-solver device state */
+
+int pycllp_hip_abi_version(void);
+const char *pycllp_hip_last_error(void);
+void pycllp_hip_default_opts(pycllp_hip_opts *opts);
+
+/* Largest (m, n) the compiled kernels accept (n counts ALL columns of the equality form). */
+int pycllp_hip_dense_max_rows(void);
+int pycllp_hip_dense_max_cols(void);
+
+/* Upload/pack the shared constraint matrix.  A_dev: [m, n] row-major f64 on the device.
+ * Synchronises `stream` before returning (A_dev may be freed by the caller afterwards). */
+int pycllp_hip_dense_init(int m, int n, const double *A_dev, void *stream, pycllp_hip_dense **handle);
+
+/* Solve B LPs.  Inputs b_dev [B,m], c_dev [B,n].  Outputs (any of y/z/pobj/dobj/iters may be NULL):
+ *   x_dev [B,n], y_dev [B,m], z_dev [B,n]  primal, dual and dual-slack solutions
+ *   pobj_dev, dobj_dev [B]                 c'x and b'y at exit (objective offset f NOT added)
+ *   status_dev [B] i32, iters_dev [B] i32  status code and IPM iterations used
+ * Asynchronous on `stream`. */
+int pycllp_hip_dense_solve(pycllp_hip_dense *handle, long B, const double *b_dev, const double *c_dev,
+                           double *x_dev, double *y_dev, double *z_dev, double *pobj_dev,
+                           double *dobj_dev, int *status_dev, int *iters_dev,
+                           const pycllp_hip_opts *opts, void *stream);
+
+/* One Newton step of the primal normal equations for B independent states:
+ *   dy <- solve( A diag(x/z) A' , -(b - A x - A diag(x/z) (c - A'y + mu/x)) )
+ * x,z,c [B,n]; y,b,dy [B,m].  nrefine_dev [B] (optional) receives the refinement passes used. */
+int pycllp_hip_dense_newton(pycllp_hip_dense *handle, long B, const double *x_dev, const double *z_dev,
+                            const double *y_dev, const double *b_dev, const double *c_dev, double mu,
+                            double *dy_dev, int *nrefine_dev, const pycllp_hip_opts *opts, void *stream);
+
+/* Kernel-level statistics of the last solve launch on this handle (host values). */
+int pycllp_hip_dense_launch_info(const pycllp_hip_dense *handle, int *grid, int *block, int *lds_bytes,
+                                 int *m_pad, int *n_pad);
+
+void pycllp_hip_dense_free(pycllp_hip_dense *handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYCLLP_HIP_H */

@@ -1,0 +1,329 @@
+/*
+ * oracle/ipm_dense_ref.c -- TEST INFRASTRUCTURE, NOT THE PRODUCT.
+ *
+ * Plain-C, single-LP-at-a-time CPU restatement of the reference's batched dense
+ * primal-normal-equations interior-point path (pycllp/cl/primal_normal.cl +
+ * pycllp/cl/ldl.cl, hosted by pycllp/solvers/cl.py).  It exists so that tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg can check / time the
+ * HIP kernels against an independent implementation of the same algorithm.
+ * Nothing under pycllp_amd/ may import, link or call this file.
+ *
+ * Parity pinning: the objectives this restatement produces are pinned against
+ * the reference's own CPU solver (pycllp/ipo.py -> ipo/hsd.c, compiled from
+ * the reference sources into oracle/_ref/ by oracle/Makefile) through
+ * tests/golden/*.npz (tools/gen_golden.py) and tests/test_oracle.py, and the
+ * Newton-step solve is pinned by the known-answer formula of the reference's
+ * tests/test_ldl.py:196-216.
+ *
+ * Semantic picks where the OpenCL kernel and its CPU twin (solvers/normal_eqns.py,
+ * _ldl.pyx) disagree follow SURVEY.md section 8(a) "divergence" table:
+ *   - stopping rule: RELATIVE eps on |rho|, |sigma|, gamma (reference: absolute
+ *     EPS 1e-7f, primal_normal.cl:8,256) -- required to reach 1e-8 objective parity
+ *     with ipo.py; the 10x growth exits (primal_normal.cl:261-269) are kept with the
+ *     same relative floor;
+ *   - centering DELTA=0.02, mu = delta*gamma/(n+m) (primal_normal.cl:10,272);
+ *   - step: theta starts at 0 so the step is clamped to <=1 (primal_normal.cl:134,143);
+ *   - beta = sqrt(max |diag M|) (ldl.cl:280-294);
+ *   - refinement with |r|, "+=" update, <=5 passes, tol 1e-8 (ldl.cl:642-652,535);
+ *   - NaN guard -> status 3 (normal_eqns.py:85-87).
+ *
+ * Unlike the reference, M = A diag(x/z) A' is formed once per iteration instead of
+ * being recomputed entry by entry inside factor/rhs/residual (ldl.cl:110-138,198-219,
+ * 577-599); the arithmetic per entry is the same sum over columns.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct oracle_opts {
+    double eps;         /* relative stopping tolerance (default 1e-10)            */
+    double delta;       /* centering parameter DELTA   (primal_normal.cl:10)       */
+    double r;           /* step fraction R             (primal_normal.cl:11)       */
+    double pivot_floor; /* LDL' diagonal floor `delta` (primal_normal.cl:275)      */
+    double refine_tol;  /* refinement tolerance        (ldl.cl:645)                */
+    int max_iter;       /* MAX_ITER                    (primal_normal.cl:9)        */
+    int max_refine;     /* refinement passes           (ldl.cl:645)                */
+    int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219) */
+} oracle_opts;
+
+void oracle_default_opts(oracle_opts *o) {
+    o->eps = 1e-10;
+    o->delta = 0.02;
+    o->r = 0.9;
+    o->pivot_floor = 1e-6;
+    o->refine_tol = 1e-8;
+    o->max_iter = 200;
+    o->max_refine = 5;
+    o->flags = 0;
+}
+
+/* packed lower-triangular index, ldl.cl:12-18 (per-LP, no batch interleave) */
+static inline int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+/* ---- stand-alone LDL' kernels on explicit matrices (ldl.cl:28-55, 57-107; ldl.py:58-112) ---- */
+
+/* plain LDL' of a dense symmetric n x n matrix, row-major; L packed, unit diagonal */
+void oracle_ldl(int n, const double *A, double *L, double *D) {
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < i; j++) {
+            double l = A[i * n + j];
+            for (int k = 0; k < j; k++) l -= L[tri(i, k)] * L[tri(j, k)] * D[k];
+            L[tri(i, j)] = l / D[j];
+        }
+        double d = A[i * n + i];
+        for (int k = 0; k < i; k++) d -= D[k] * L[tri(i, k)] * L[tri(i, k)];
+        D[i] = d;
+        L[tri(i, i)] = 1.0;
+    }
+}
+
+/* modified LDL' (Nocedal & Wright alg. 3.4 diagonal guard), ldl.cl:57-107 */
+void oracle_modified_ldl(int n, const double *A, double *L, double *D, double beta, double delta) {
+    for (int j = 0; j < n; j++) {
+        double Dj = A[j * n + j];
+        for (int k = 0; k < j; k++) Dj -= D[k] * L[tri(j, k)] * L[tri(j, k)];
+        double theta = 0.0;
+        for (int i = j + 1; i < n; i++) {
+            double l = A[i * n + j];
+            for (int k = 0; k < j; k++) l -= L[tri(i, k)] * L[tri(j, k)] * D[k];
+            theta = fmax(theta, fabs(l));
+            L[tri(i, j)] = l;
+        }
+        double tb = theta / beta;
+        Dj = fmax(fabs(Dj), fmax(tb * tb, delta));
+        for (int i = j + 1; i < n; i++) L[tri(i, j)] /= Dj;
+        D[j] = Dj;
+        L[tri(j, j)] = 1.0;
+    }
+}
+
+/* S <- (L D L')^-1 S, forward then backward substitution, ldl.cl:505-537 */
+void oracle_forward_backward(int m, const double *L, const double *D, double *S) {
+    for (int i = 0; i < m; i++) {
+        double s = S[i];
+        for (int j = 0; j < i; j++) s -= S[j] * L[tri(i, j)] * D[j];
+        S[i] = s / D[i];
+    }
+    for (int j = m - 1; j >= 0; j--) {
+        double s = S[j];
+        for (int i = j + 1; i < m; i++) s -= S[i] * L[tri(i, j)];
+        S[j] = s;
+    }
+}
+
+/* ---- the Newton step of the primal normal equations (ldl.cl:602-653) ---- */
+
+typedef struct work {
+    double *M, *L, *D, *S, *rhs, *dy, *d, *t, *w, *rho, *sigma;
+} work;
+
+static void work_alloc(work *wk, int m, int N) {
+    wk->M = (double *)malloc(sizeof(double) * m * m);
+    wk->L = (double *)malloc(sizeof(double) * (m * (m + 1) / 2));
+    wk->D = (double *)malloc(sizeof(double) * m);
+    wk->S = (double *)malloc(sizeof(double) * m);
+    wk->rhs = (double *)malloc(sizeof(double) * m);
+    wk->dy = (double *)malloc(sizeof(double) * m);
+    wk->rho = (double *)malloc(sizeof(double) * m);
+    wk->d = (double *)malloc(sizeof(double) * N);
+    wk->t = (double *)malloc(sizeof(double) * N);
+    wk->w = (double *)malloc(sizeof(double) * N);
+    wk->sigma = (double *)malloc(sizeof(double) * N);
+}
+
+static void work_free(work *wk) {
+    free(wk->M); free(wk->L); free(wk->D); free(wk->S); free(wk->rhs); free(wk->dy);
+    free(wk->rho); free(wk->d); free(wk->t); free(wk->w); free(wk->sigma);
+}
+
+/* M = A diag(x/z) A' (ldl.cl:110-138), lower triangle mirrored */
+static void gram(int m, int N, const double *A, const double *d, double *M) {
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j <= i; j++) {
+            double a = 0.0;
+            for (int k = 0; k < N; k++) a += A[i * N + k] * d[k] * A[j * N + k];
+            M[i * m + j] = a;
+            M[j * m + i] = a;
+        }
+}
+
+/* factor (ldl.cl:314-378): beta from the diagonal (ldl.cl:280-294), then modified LDL' */
+static void factor(int m, const double *M, double *L, double *D, double floor_) {
+    double beta = 0.0;
+    for (int j = 0; j < m; j++) beta = fmax(beta, fabs(M[j * m + j]));
+    beta = sqrt(beta);
+    oracle_modified_ldl(m, M, L, D, beta, floor_);
+}
+
+/*
+ * dy <- solution of  M dy = -(b - A x - A (x/z)(c - A'y + mu/x))   (ldl.cl:198-219, 602-653)
+ * with <= max_refine refinement passes on the unperturbed M (ldl.cl:642-652).
+ * Returns the number of refinement passes used.
+ */
+static int newton_dy(int m, int N, const double *A, const double *x, const double *z, const double *y,
+                     const double *b, const double *c, double mu, const oracle_opts *o, work *wk) {
+    double *d = wk->d, *t = wk->t;
+    for (int k = 0; k < N; k++) {
+        double aty = 0.0;
+        for (int i = 0; i < m; i++) aty += A[i * N + k] * y[i];
+        d[k] = x[k] / z[k];
+        t[k] = c[k] - aty + mu / x[k];
+    }
+    gram(m, N, A, d, wk->M);
+    factor(m, wk->M, wk->L, wk->D, o->pivot_floor);
+    for (int i = 0; i < m; i++) {
+        double rhs = b[i];
+        for (int k = 0; k < N; k++) {
+            rhs += -A[i * N + k] * x[k];
+            rhs += -A[i * N + k] * d[k] * t[k];
+        }
+        wk->rhs[i] = -rhs;
+        wk->S[i] = -rhs;
+        wk->dy[i] = 0.0;
+    }
+    int nref = 0;
+    for (;;) {
+        oracle_forward_backward(m, wk->L, wk->D, wk->S);
+        for (int i = 0; i < m; i++) wk->dy[i] += wk->S[i];
+        double maxr = 0.0;
+        for (int i = 0; i < m; i++) {
+            double r = wk->rhs[i];
+            for (int j = 0; j < m; j++) r -= wk->M[i * m + j] * wk->dy[j];
+            wk->S[i] = r;
+            maxr = fmax(maxr, fabs(r));
+        }
+        if (!(maxr > o->refine_tol) || nref >= o->max_refine) break;
+        nref++;
+    }
+    return nref;
+}
+
+/* exported single Newton step: mirrors the `solve_primal_normal` kernel as launched by
+ * the reference tests (tests/test_ldl.py:219-273) */
+int oracle_solve_primal_normal(int m, int N, const double *A, const double *x, const double *z,
+                               const double *y, const double *b, const double *c, double mu,
+                               double pivot_floor, double *dy) {
+    oracle_opts o;
+    oracle_default_opts(&o);
+    o.pivot_floor = pivot_floor;
+    work wk;
+    work_alloc(&wk, m, N);
+    int nref = newton_dy(m, N, A, x, z, y, b, c, mu, &o, &wk);
+    memcpy(dy, wk.dy, sizeof(double) * m);
+    work_free(&wk);
+    return nref;
+}
+
+/*
+ * One LP: max c'x s.t. Ax = b, x >= 0 (equality form, lp.py:306-330), the loop of
+ * primal_normal.cl:201-284 with the step of primal_normal.cl:122-156.
+ */
+static int ipm_one(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                   double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                   work *wk) {
+    int stat = 5;
+    if (!(o->flags & 1)) { /* initialize_xzyw, primal_normal.cl:14-28 */
+        for (int j = 0; j < N; j++) { x[j] = 1.0; z[j] = 1.0; }
+        for (int i = 0; i < m; i++) y[i] = 1.0;
+    }
+    double nb = 0.0, nc = 0.0;
+    for (int i = 0; i < m; i++) nb += b[i] * b[i];
+    for (int j = 0; j < N; j++) nc += c[j] * c[j];
+    const double tol_r = o->eps * (1.0 + sqrt(nb));
+    const double tol_s = o->eps * (1.0 + sqrt(nc));
+    double normr0 = 1e300, norms0 = 1e300;
+    int it, totref = 0;
+    double po = 0.0, du = 0.0;
+    for (it = 0; it < o->max_iter; it++) {
+        /* primal_infeasibility, primal_normal.cl:30-48 */
+        double normr = 0.0;
+        for (int i = 0; i < m; i++) {
+            double rho = b[i];
+            for (int j = 0; j < N; j++) rho -= A[i * N + j] * x[j];
+            wk->rho[i] = rho;
+            normr += rho * rho;
+        }
+        normr = sqrt(normr);
+        /* dual_infeasibility, primal_normal.cl:76-94 */
+        double norms = 0.0;
+        for (int j = 0; j < N; j++) {
+            double sigma = c[j] + z[j];
+            for (int i = 0; i < m; i++) sigma += -A[i * N + j] * y[i];
+            norms += sigma * sigma;
+        }
+        norms = sqrt(norms);
+        /* complementarity, primal_normal.cl:245-248 */
+        double gamma = 0.0;
+        po = 0.0; du = 0.0;
+        for (int j = 0; j < N; j++) { gamma += z[j] * x[j]; po += c[j] * x[j]; }
+        for (int i = 0; i < m; i++) du += b[i] * y[i];
+
+        if (!(isfinite(normr) && isfinite(norms) && isfinite(gamma))) { stat = 3; break; }
+        if (normr <= tol_r && norms <= tol_s && gamma <= o->eps * (1.0 + fabs(po))) { stat = 0; break; }
+        if (normr > 10 * normr0 && normr > tol_r) { stat = 2; break; }
+        if (norms > 10 * norms0 && norms > tol_s) { stat = 4; break; }
+
+        double mu = o->delta * gamma / (N + m); /* primal_normal.cl:272 */
+        totref += newton_dy(m, N, A, x, z, y, b, c, mu, o, wk);
+        const double *dy = wk->dy;
+        int bad = 0;
+        for (int i = 0; i < m; i++) if (!isfinite(dy[i])) bad = 1;
+        if (bad) { stat = 3; break; }
+
+        /* primal_normal_step, primal_normal.cl:122-156 */
+        double theta = 0.0;
+        double *dx = wk->w, *dz = wk->sigma;
+        for (int j = 0; j < N; j++) {
+            double aty = 0.0, atdy = 0.0;
+            for (int i = 0; i < m; i++) { aty += A[i * N + j] * y[i]; atdy += A[i * N + j] * dy[i]; }
+            dx[j] = (c[j] - aty + mu / x[j] - atdy) * x[j] / z[j];
+            dz[j] = (mu - z[j] * dx[j]) / x[j] - z[j];
+            theta = fmax(theta, fmax(-dz[j] / z[j], -dx[j] / x[j]));
+        }
+        theta = fmin(o->r / theta, 1.0);
+        for (int i = 0; i < m; i++) y[i] += theta * dy[i];
+        for (int j = 0; j < N; j++) { z[j] += theta * dz[j]; x[j] += theta * dx[j]; }
+        normr0 = normr;
+        norms0 = norms;
+    }
+    *pobj = po;
+    *dobj = du;
+    *iters = it;
+    if (nrefs) *nrefs = totref;
+    return stat;
+}
+
+/*
+ * Batched driver with the reference's problem-major layout (lp.py:338-347):
+ * A [m,N] row-major shared; b [B,m]; c [B,N]; outputs x [B,N], y [B,m], z [B,N],
+ * pobj/dobj [B], status/iters/nrefs [B].  nthreads<=1 -> serial.
+ */
+int oracle_dense_solve(int m, int N, const double *A, long B, const double *b, const double *c, double *x,
+                       double *y, double *z, double *pobj, double *dobj, int *status, int *iters,
+                       int *nrefs, const oracle_opts *opts, int nthreads) {
+    oracle_opts o;
+    if (opts) o = *opts; else oracle_default_opts(&o);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        work wk;
+        work_alloc(&wk, m, N);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+        for (long p = 0; p < B; p++) {
+            int it = 0, nr = 0;
+            status[p] = ipm_one(m, N, A, b + p * m, c + p * N, x + p * N, y + p * m, z + p * N, pobj + p,
+                                dobj + p, &it, &nr, &o, &wk);
+            iters[p] = it;
+            if (nrefs) nrefs[p] = nr;
+        }
+        work_free(&wk);
+    }
+    return 0;
+}

@@ -1,0 +1,86 @@
+"""ctypes loader for csrc/libpycllp_hip.so (C ABI: include/pycllp_hip.h).
+
+The library is the product; there is NO fallback.  A missing library raises ``RuntimeError`` at first
+use, and the solvers refuse to run without a ROCm device.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpycllp_hip.so")
+
+# every symbol include/pycllp_hip.h declares (tests/test_abi.py checks the two stay in sync)
+EXPORTS = (
+    "pycllp_hip_abi_version", "pycllp_hip_last_error", "pycllp_hip_default_opts",
+    "pycllp_hip_dense_max_rows", "pycllp_hip_dense_max_cols", "pycllp_hip_dense_init",
+    "pycllp_hip_dense_solve", "pycllp_hip_dense_newton", "pycllp_hip_dense_launch_info",
+    "pycllp_hip_dense_free",
+)
+
+STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
+FLAG_WARM_START = 1
+
+
+class Opts(ctypes.Structure):
+    """Mirror of ``pycllp_hip_opts``."""
+    _fields_ = [("eps", ctypes.c_double), ("delta", ctypes.c_double), ("r", ctypes.c_double),
+                ("pivot_floor", ctypes.c_double), ("refine_tol", ctypes.c_double),
+                ("max_iter", ctypes.c_int), ("max_refine", ctypes.c_int), ("flags", ctypes.c_int),
+                ("reserved", ctypes.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pycllp_amd: HIP library %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C pycllp_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, dp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+    L.pycllp_hip_abi_version.restype = ctypes.c_int
+    L.pycllp_hip_last_error.restype = ctypes.c_char_p
+    L.pycllp_hip_default_opts.argtypes = [ctypes.POINTER(Opts)]
+    L.pycllp_hip_default_opts.restype = None
+    L.pycllp_hip_dense_max_rows.restype = ctypes.c_int
+    L.pycllp_hip_dense_max_cols.restype = ctypes.c_int
+    L.pycllp_hip_dense_init.argtypes = [ctypes.c_int, ctypes.c_int, dp, vp, ctypes.POINTER(vp)]
+    L.pycllp_hip_dense_init.restype = ctypes.c_int
+    L.pycllp_hip_dense_solve.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, dp, dp, ip, ip,
+                                         ctypes.POINTER(Opts), vp]
+    L.pycllp_hip_dense_solve.restype = ctypes.c_int
+    L.pycllp_hip_dense_newton.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, ctypes.c_double, dp, ip,
+                                          ctypes.POINTER(Opts), vp]
+    L.pycllp_hip_dense_newton.restype = ctypes.c_int
+    L.pycllp_hip_dense_launch_info.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int)] * 5
+    L.pycllp_hip_dense_launch_info.restype = ctypes.c_int
+    L.pycllp_hip_dense_free.argtypes = [vp]
+    L.pycllp_hip_dense_free.restype = None
+    if L.pycllp_hip_abi_version() != 1:
+        raise RuntimeError("pycllp_amd: ABI version mismatch in %s" % LIB_PATH)
+    _lib = L
+    return L
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().pycllp_hip_default_opts(ctypes.byref(o))
+    for k, v in kw.items():
+        if k not in dict(Opts._fields_) or k == "reserved":
+            raise TypeError("unknown solver option %r" % k)
+        setattr(o, k, v)
+    return o
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pycllp_hip_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError("%s: %s" % (what, msg))
+        if rc < 0:
+            raise ValueError("%s: %s" % (what, msg))
+        raise RuntimeError("%s failed (hipError %d): %s" % (what, rc, msg))

@@ -1,0 +1,710 @@
+// ipm_dense.hip -- batched dense primal-normal-equations interior-point LP solver for MI355X (gfx950).
+//
+// What it replaces in the reference (jetuk/pycllp): the OpenCL kernels pycllp/cl/primal_normal.cl
+// (standard_primal_normal :201-284, primal_normal_step :122-156, initialize_xzyw :14-28) and
+// pycllp/cl/ldl.cl (factor_primal_normal :314-378, forward_backward_primal_normal :505-537,
+// residual_primal_normal :577-599, solve_primal_normal :602-653), hosted by pycllp/solvers/cl.py.
+//
+// Design (CDNA4-first, not a translation): the reference maps one LP to one work-item and re-reads
+// x, z from global memory for every matrix entry.  Here ONE LP IS OWNED BY ONE 64-LANE WAVEFRONT for
+// its whole solve; its state never leaves the CU:
+//   * N-vectors (x, z, c, A'y, ...) live in registers, lane = column (columns lane and lane+64);
+//   * m-vectors (y, b, rho, dy, ...) live in registers, lane = row (lane mod MP);
+//   * the shared constraint matrix A sits in LDS once per workgroup, in two images: the operand order
+//     of v_mfma_f64_16x16x4_f64 (for the Gram product and the A*v products) and row-major (for A'u);
+//   * the Gram matrix M = A diag(x/z) A' is a true dense contraction and runs on the matrix cores
+//     (MFMA f64 16x16x4, symmetric: only the lower 16x16 blocks), fused with A*x and A*(d.t);
+//   * M goes through LDS once to turn the MFMA accumulator layout into "lane = row"; the modified
+//     LDL' factorisation then runs out of registers (row i of the trailing matrix in lane i), the
+//     transposed factor is staged in the wave's private LDS slab for the triangular solves;
+//   * HBM traffic is the compulsory b, c in and x, y, z, objectives, status out: 16(m+N)+8N+24 B/LP.
+// Workgroups are persistent: each wave strides over the batch.
+//
+// Numerical semantics follow oracle/ipm_dense_ref.c (the CPU restatement used by the tests), i.e. the
+// reference algorithm with the SURVEY section 8(a) picks: relative stopping tolerance, DELTA/R of the
+// OpenCL kernel, Nocedal-Wright diagonal guard, |r|-driven iterative refinement, NaN guard.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pycllp_hip.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double v, int srclane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, srclane);
+    hi = __builtin_amdgcn_readlane(hi, srclane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// Wave-private LDS hand-off: DS operations of one wave execute in order, so only the compiler has
+// to be kept from moving a read above the write it depends on.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct DevOpts {
+    double eps, delta, r, pivot_floor, refine_tol;
+    int max_iter, max_refine, flags;
+};
+
+// ------------------------------------------------------------------------------------------------
+// compile-time geometry
+// ------------------------------------------------------------------------------------------------
+template <int MP, int NP>
+struct Geo {
+    static_assert(MP == 16 || MP == 32, "row padding must be 16 or 32");
+    static_assert(NP % 8 == 0 && NP >= 8 && NP <= 128, "column padding must be a multiple of 8, <= 128");
+    static constexpr int JB = MP / 16;           // 16-row blocks of A
+    static constexpr int KS = NP / 4;            // k-steps of the 16x16x4 MFMA
+    static constexpr int NC = (NP > 64) ? 2 : 1; // columns per lane
+    static constexpr int NL = 64 * NC;           // row-major image row length
+    static constexpr int MS = MP + 2;            // row stride of the wave's matrix slab (16-B aligned rows,
+                                                 // conflict-free b128 row reads)
+    static constexpr int AMF = JB * KS * 64;     // doubles in the MFMA-order image
+    static constexpr int ARM = MP * NL;          // doubles in the row-major image
+    static constexpr int APACK = AMF + ARM;
+    static constexpr int WSLAB = MP * MS + 3 * NP; // per-wave doubles: matrix slab + 3 k-layout vectors
+    static constexpr size_t lds_bytes(int wpb) { return sizeof(double) * (size_t)(APACK + wpb * WSLAB); }
+    // position of column j in a k-layout vector: lane group g = j&3 reads KS consecutive values
+    __host__ __device__ static constexpr int kpos(int j) { return (j & 3) * KS + (j >> 2); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pack kernel: A [m,n] row-major  ->  [ MFMA-operand image | row-major padded image ]
+//   Amf[J][s][l] = A[16J + (l&15)][4s + (l>>4)]   (A/B operand lane map of v_mfma_f64_16x16x4_f64)
+//   Arm[i][j]    = A[i][j]   (zero padded to MP x NL)
+// ------------------------------------------------------------------------------------------------
+template <int MP, int NP>
+__global__ void pack_A_kernel(int m, int n, const double* __restrict__ A, double* __restrict__ pack) {
+    using G = Geo<MP, NP>;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < G::AMF) {
+        int l = idx & 63, s = (idx >> 6) % G::KS, J = (idx >> 6) / G::KS;
+        int row = 16 * J + (l & 15), col = 4 * s + (l >> 4);
+        pack[idx] = (row < m && col < n) ? A[(size_t)row * n + col] : 0.0;
+    } else if (idx < G::APACK) {
+        int k = idx - G::AMF;
+        int row = k / G::NL, col = k % G::NL;
+        pack[idx] = (row < m && col < n) ? A[(size_t)row * n + col] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-wave Newton machinery
+// ------------------------------------------------------------------------------------------------
+template <int MP, int NP>
+struct Wave {
+    using G = Geo<MP, NP>;
+    static constexpr int JB = G::JB, KS = G::KS, NC = G::NC, MS = G::MS;
+
+    const double* Amf;  // LDS, MFMA-order image
+    const double* Arm;  // LDS, row-major image
+    double* slab;       // LDS, wave-private MP x MS matrix slab
+    double* kx;         // LDS, wave-private k-layout vectors
+    double* kd;
+    double* kdt;
+    int lane, ri, m, n;
+
+    // v_q = sum_i A[i][col_q] * u[i]   (u in lane=row layout)  -- A'u, reference primal_normal.cl:138-141
+    __device__ __forceinline__ void At_times(double u, double out[NC]) const {
+#pragma unroll
+        for (int q = 0; q < NC; q++) out[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < MP; i++) {
+            double ui = readlane_d(u, i);
+#pragma unroll
+            for (int q = 0; q < NC; q++) out[q] = fma(Arm[i * G::NL + lane + 64 * q], ui, out[q]);
+        }
+    }
+
+    // Gram product on the matrix cores, fused with A*x and A*(d.t).
+    // In: kx, kd, kdt hold x, d = x/z and d*t in k-layout.  Out: M written to the slab (full symmetric),
+    // Ax / Adt in lane=row layout.
+    __device__ __forceinline__ void gram_fused(double& Ax, double& Adt) const {
+        const int g = lane >> 4;
+        double4_t acc[JB][JB];
+        double axp[JB], adp[JB];
+#pragma unroll
+        for (int I = 0; I < JB; I++) {
+            axp[I] = 0.0; adp[I] = 0.0;
+#pragma unroll
+            for (int J = 0; J < JB; J++) acc[I][J] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        const double* px = kx + g * KS;
+        const double* pd = kd + g * KS;
+        const double* pt = kdt + g * KS;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            double xk = px[s], dk = pd[s], tk = pt[s];
+            double a[JB], ad[JB];
+#pragma unroll
+            for (int J = 0; J < JB; J++) {
+                a[J] = Amf[(J * KS + s) * 64 + lane];
+                axp[J] = fma(a[J], xk, axp[J]);
+                adp[J] = fma(a[J], tk, adp[J]);
+                ad[J] = a[J] * dk;
+            }
+#pragma unroll
+            for (int I = 0; I < JB; I++)
+#pragma unroll
+                for (int J = 0; J <= I; J++)
+                    acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[I], a[J], acc[I][J], 0, 0, 0);
+        }
+        // accumulator (I,J), register r4: row 16I + (lane>>4) + 4*r4, col 16J + (lane&15)
+        const int cc = lane & 15;
+#pragma unroll
+        for (int I = 0; I < JB; I++)
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    int row = 16 * I + g + 4 * r4, col = 16 * J + cc;
+                    double v = acc[I][J][r4];
+                    slab[row * MS + col] = v;
+                    if (I != J) slab[col * MS + row] = v;
+                }
+        // reduce the A*v partials over the 4 lane groups; pick this lane's row block
+#pragma unroll
+        for (int J = 0; J < JB; J++) {
+            axp[J] += __shfl_xor(axp[J], 16, WAVE);
+            axp[J] += __shfl_xor(axp[J], 32, WAVE);
+            adp[J] += __shfl_xor(adp[J], 16, WAVE);
+            adp[J] += __shfl_xor(adp[J], 32, WAVE);
+        }
+        if (JB == 1) { Ax = axp[0]; Adt = adp[0]; }
+        else {
+            const bool hiblk = (ri >> 4) & 1;
+            Ax = hiblk ? axp[JB - 1] : axp[0];
+            Adt = hiblk ? adp[JB - 1] : adp[0];
+        }
+    }
+
+    // Modified LDL' (Nocedal-Wright 3.4 guard, ldl.cl:314-378) of the matrix whose row `ri` is in W.
+    // On exit: slab[j*MS + i] = L[i][j] for i>j (0 elsewhere), rdiag = 1/D[ri].
+    __device__ __forceinline__ void factor(double (&W)[MP], double beta2, double floor_, double& rdiag) const {
+        rdiag = 1.0;
+#pragma unroll
+        for (int j = 0; j < MP; j++) {
+            const double u = W[j];
+            const double piv = readlane_d(u, j);
+            double aD = fmax(fabs(piv), floor_);
+            const bool below = ri > j;
+            // guard: D_j = max(|D_j|, (theta/beta)^2, floor) with theta = max_{i>j} |u_i|; it only bites when
+            // some u_i^2 > beta^2 * max(|D_j|, floor), which one ballot detects
+            if (__any(below && (u * u > beta2 * aD))) {
+                double theta = wave_max(below ? fabs(u) : 0.0);
+                aD = fmax(aD, theta * theta / beta2);
+            }
+            const double rD = 1.0 / aD;
+            const double l = below ? u * rD : 0.0;
+            if (ri == j) rdiag = rD;
+            slab[j * MS + ri] = l;  // lanes >= MP write the same value as their twin: benign
+            if (j + 1 < MP) {
+                wave_lds_sync();
+                const double* Lj = slab + j * MS;
+#pragma unroll
+                for (int k = j + 1; k < MP; k++) W[k] = fma(-u, Lj[k], W[k]);
+            }
+        }
+        wave_lds_sync();
+    }
+
+    // s <- (L D L')^-1 s  (ldl.cl:505-537), s in lane=row layout
+    __device__ __forceinline__ double fwd_back(double s, double rdiag) const {
+        // forward, column oriented: t_i -= L[i][k] t_k
+#pragma unroll
+        for (int k = 0; k < MP - 1; k++) {
+            double tk = readlane_d(s, k);
+            s = fma(-slab[k * MS + ri], tk, s);
+        }
+        s *= rdiag;
+        // backward, column oriented: s_j -= L[i][j] s_i for j < i; lane j owns row j of the slab
+        double Lt[MP];
+        const double* row = slab + ri * MS;
+#pragma unroll
+        for (int i = 0; i < MP; i++) Lt[i] = row[i];
+#pragma unroll
+        for (int i = MP - 1; i >= 1; i--) {
+            double si = readlane_d(s, i);
+            s = fma(-Lt[i], si, s);
+        }
+        return s;
+    }
+
+    // M*v with row ri of M in Mrow, v in lane=row layout
+    __device__ __forceinline__ double M_times(const double (&Mrow)[MP], double v) const {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < MP; k++) acc = fma(Mrow[k], readlane_d(v, k), acc);
+        return acc;
+    }
+
+    // Newton step dy of the primal normal equations (ldl.cl:602-653) given x, z, c, v=A'y, b, mu.
+    // Returns dy (lane=row); outputs d, t (per column), rho and the refinement count.
+    __device__ __forceinline__ double newton(const double (&x)[NC], const double (&z)[NC], const double (&c)[NC],
+                                             const double (&v)[NC], double b, double mu, const DevOpts& o,
+                                             double (&d)[NC], double (&t)[NC], double& rho, int& nref) const {
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int j = lane + 64 * q;
+            const bool ok = j < n;
+            d[q] = ok ? x[q] / z[q] : 0.0;
+            t[q] = ok ? c[q] - v[q] + mu / x[q] : 0.0;
+            if (j < NP) {
+                const int p = G::kpos(j);
+                kx[p] = ok ? x[q] : 0.0;
+                kd[p] = d[q];
+                kdt[p] = d[q] * t[q];
+            }
+        }
+        wave_lds_sync();
+        double Ax, Adt;
+        gram_fused(Ax, Adt);
+        rho = b - Ax;                       // primal_normal.cl:30-48
+        const double rhs = Adt - rho;       // -(b - Ax - A d t), ldl.cl:198-219
+        wave_lds_sync();
+        // pull row ri of M out of the slab; padded rows become identity rows
+        double W[MP], Mrow[MP];
+        {
+            const double* row = slab + ri * MS;
+#pragma unroll
+            for (int k = 0; k < MP; k++) W[k] = row[k];
+        }
+        double diag = slab[ri * MS + ri];
+        if (ri >= m) {
+#pragma unroll
+            for (int k = 0; k < MP; k++) W[k] = (k == ri) ? 1.0 : W[k];
+            diag = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < MP; k++) Mrow[k] = W[k];
+        const double beta2 = wave_max(fabs(diag));  // beta^2 = max |M_ii|, ldl.cl:280-294
+        wave_lds_sync();
+        double rdiag;
+        factor(W, beta2, o.pivot_floor, rdiag);
+        // solve + refinement on the unperturbed M (ldl.cl:632-652)
+        double dy = 0.0, s = rhs;
+        nref = 0;
+        for (;;) {
+            s = fwd_back(s, rdiag);
+            dy += s;
+            s = rhs - M_times(Mrow, dy);
+            const double maxr = wave_max(fabs(s));
+            if (!(maxr > o.refine_tol) || nref >= o.max_refine) break;
+            nref++;
+        }
+        return dy;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// solve kernel: standard_primal_normal (primal_normal.cl:201-284), one LP per wavefront, persistent
+// ------------------------------------------------------------------------------------------------
+template <int MP, int NP>
+__global__ void __launch_bounds__(512)
+ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const double* __restrict__ bg,
+                 const double* __restrict__ cg, double* __restrict__ xg, double* __restrict__ yg,
+                 double* __restrict__ zg, double* __restrict__ pobj, double* __restrict__ dobj,
+                 int* __restrict__ status, int* __restrict__ iters, DevOpts o) {
+    using G = Geo<MP, NP>;
+    constexpr int NC = G::NC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int wpb = blockDim.x / WAVE;
+    // stage both images of A (shared by the workgroup's waves)
+    for (int i = tid; i < G::APACK; i += blockDim.x) lds[i] = pack[i];
+    __syncthreads();
+
+    Wave<MP, NP> w;
+    const int wave = tid / WAVE;
+    w.lane = tid & 63;
+    w.ri = w.lane & (MP - 1);
+    w.m = m; w.n = n;
+    w.Amf = lds;
+    w.Arm = lds + G::AMF;
+    w.slab = lds + G::APACK + wave * G::WSLAB;
+    w.kx = w.slab + MP * G::MS;
+    w.kd = w.kx + NP;
+    w.kdt = w.kd + NP;
+    const int lane = w.lane, ri = w.ri;
+    const bool rowok = ri < m;
+    const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+
+    for (long lp = (long)blockIdx.x * wpb + wave; lp < B; lp += (long)gridDim.x * wpb) {
+        double x[NC], z[NC], c[NC], v[NC];
+        bool ok[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int j = lane + 64 * q;
+            ok[q] = j < n;
+            c[q] = ok[q] ? cg[lp * n + j] : 0.0;
+            x[q] = (warm && ok[q]) ? xg[lp * n + j] : 1.0;
+            z[q] = (warm && ok[q]) ? zg[lp * n + j] : 1.0;
+        }
+        const double b = rowok ? bg[lp * m + ri] : 0.0;
+        double y = rowok ? ((warm && yg) ? yg[lp * m + ri] : 1.0) : 0.0;
+        w.At_times(y, v);
+
+        double nb2 = wave_sum((lane < MP) ? b * b : 0.0);
+        double nc2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NC; q++) nc2 += c[q] * c[q];
+        nc2 = wave_sum(nc2);
+        const double tol_r = o.eps * (1.0 + sqrt(nb2));
+        const double tol_s = o.eps * (1.0 + sqrt(nc2));
+        double normr0 = 1e300, norms0 = 1e300;
+        int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
+        double po = 0.0, du = 0.0;
+
+        for (it = 0; it < o.max_iter; it++) {
+            // dual infeasibility, complementarity, objectives (primal_normal.cl:76-94, 245-248)
+            double s2 = 0.0, gam = 0.0, pp = 0.0;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const double sg = ok[q] ? c[q] - v[q] + z[q] : 0.0;
+                s2 = fma(sg, sg, s2);
+                gam += ok[q] ? x[q] * z[q] : 0.0;
+                pp += c[q] * (ok[q] ? x[q] : 0.0);
+            }
+            s2 = wave_sum(s2); gam = wave_sum(gam); po = wave_sum(pp);
+            du = wave_sum((lane < MP) ? b * y : 0.0);
+            const double norms = sqrt(s2);
+            const double mu = o.delta * gam / (double)(n + m);  // primal_normal.cl:272
+
+            // Newton step (also yields rho = b - Ax for the stop test of THIS point)
+            double d[NC], t[NC], rho;
+            int nref;
+            const double dy = w.newton(x, z, c, v, b, mu, o, d, t, rho, nref);
+            const double normr = sqrt(wave_sum((lane < MP) ? rho * rho : 0.0));
+
+            if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+            if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; break; }
+            if (normr > 10.0 * normr0 && normr > tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; break; }
+            if (norms > 10.0 * norms0 && norms > tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; break; }
+            if (__any(!isfinite(dy))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+
+            // step (primal_normal.cl:122-156)
+            double wv[NC], dx[NC], dz[NC];
+            w.At_times(dy, wv);
+            double th = 0.0;
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                dx[q] = (t[q] - wv[q]) * d[q];
+                dz[q] = ok[q] ? (mu - z[q] * dx[q]) / x[q] - z[q] : 0.0;
+                if (ok[q]) th = fmax(th, fmax(-dz[q] / z[q], -dx[q] / x[q]));
+            }
+            th = wave_max(th);
+            const double theta = fmin(o.r / th, 1.0);
+            y = fma(theta, dy, y);
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                x[q] = fma(theta, dx[q], x[q]);
+                z[q] = fma(theta, dz[q], z[q]);
+                v[q] = fma(theta, wv[q], v[q]);  // A'y carried along: A'(y + theta dy)
+            }
+            normr0 = normr;
+            norms0 = norms;
+        }
+
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int j = lane + 64 * q;
+            if (ok[q]) {
+                xg[lp * n + j] = x[q];
+                if (zg) zg[lp * n + j] = z[q];
+            }
+        }
+        if (yg && lane < MP && rowok) yg[lp * m + ri] = y;
+        if (lane == 0) {
+            if (pobj) pobj[lp] = po;
+            if (dobj) dobj[lp] = du;
+            status[lp] = stat;
+            if (iters) iters[lp] = it;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone Newton step kernel: solve_primal_normal (ldl.cl:602-653) as launched by the reference's
+// tests/test_ldl.py:219-273
+// ------------------------------------------------------------------------------------------------
+template <int MP, int NP>
+__global__ void __launch_bounds__(512)
+newton_kernel(int m, int n, long B, const double* __restrict__ pack, const double* __restrict__ xg,
+              const double* __restrict__ zg, const double* __restrict__ yg, const double* __restrict__ bg,
+              const double* __restrict__ cg, double mu, double* __restrict__ dyg, int* __restrict__ nrefg,
+              DevOpts o) {
+    using G = Geo<MP, NP>;
+    constexpr int NC = G::NC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int wpb = blockDim.x / WAVE;
+    for (int i = tid; i < G::APACK; i += blockDim.x) lds[i] = pack[i];
+    __syncthreads();
+    Wave<MP, NP> w;
+    const int wave = tid / WAVE;
+    w.lane = tid & 63;
+    w.ri = w.lane & (MP - 1);
+    w.m = m; w.n = n;
+    w.Amf = lds;
+    w.Arm = lds + G::AMF;
+    w.slab = lds + G::APACK + wave * G::WSLAB;
+    w.kx = w.slab + MP * G::MS;
+    w.kd = w.kx + NP;
+    w.kdt = w.kd + NP;
+    const int lane = w.lane, ri = w.ri;
+    for (long lp = (long)blockIdx.x * wpb + wave; lp < B; lp += (long)gridDim.x * wpb) {
+        double x[NC], z[NC], c[NC], v[NC], d[NC], t[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int j = lane + 64 * q;
+            const bool ok = j < n;
+            x[q] = ok ? xg[lp * n + j] : 1.0;
+            z[q] = ok ? zg[lp * n + j] : 1.0;
+            c[q] = ok ? cg[lp * n + j] : 0.0;
+        }
+        const double b = (ri < m) ? bg[lp * m + ri] : 0.0;
+        const double y = (ri < m) ? yg[lp * m + ri] : 0.0;
+        w.At_times(y, v);
+        double rho;
+        int nref;
+        const double dy = w.newton(x, z, c, v, b, mu, o, d, t, rho, nref);
+        if (lane < MP && ri < m) dyg[lp * m + ri] = dy;
+        if (nrefg && lane == 0) nrefg[lp] = nref;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: C ABI
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char* what) {
+    if (code > 0) snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString((hipError_t)code));
+    else snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+#define HIP_TRY(expr)                                             \
+    do {                                                          \
+        hipError_t e_ = (expr);                                   \
+        if (e_ != hipSuccess) return set_err((int)e_, #expr);     \
+    } while (0)
+
+struct pycllp_hip_dense {
+    int m, n, mp, np, variant;
+    double* pack;
+    int grid, block, lds;
+    int num_cu;
+    int max_lds;
+};
+
+typedef hipError_t (*solve_launch_fn)(pycllp_hip_dense*, long, const double*, const double*, double*, double*,
+                                      double*, double*, double*, int*, int*, DevOpts, hipStream_t);
+typedef hipError_t (*newton_launch_fn)(pycllp_hip_dense*, long, const double*, const double*, const double*,
+                                       const double*, const double*, double, double*, int*, DevOpts, hipStream_t);
+typedef hipError_t (*pack_launch_fn)(pycllp_hip_dense*, const double*, hipStream_t);
+
+template <int MP, int NP>
+static int pick_wpb(const pycllp_hip_dense* h) {
+    using G = Geo<MP, NP>;
+    int wpb = 8;
+    while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb >>= 1;
+    return wpb;
+}
+
+template <int MP, int NP>
+static void plan(pycllp_hip_dense* h, long B) {
+    using G = Geo<MP, NP>;
+    const int wpb = pick_wpb<MP, NP>(h);
+    long blocks = (B + wpb - 1) / wpb;
+    const long resident = (long)h->num_cu * ((size_t)h->max_lds / G::lds_bytes(wpb) >= 2 ? 2 : 1);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) blocks = 1;
+    h->grid = (int)blocks;
+    h->block = wpb * WAVE;
+    h->lds = (int)G::lds_bytes(wpb);
+}
+
+template <int MP, int NP>
+static hipError_t launch_pack(pycllp_hip_dense* h, const double* A, hipStream_t st) {
+    using G = Geo<MP, NP>;
+    const int threads = 256, blocks = (G::APACK + threads - 1) / threads;
+    hipLaunchKernelGGL((pack_A_kernel<MP, NP>), dim3(blocks), dim3(threads), 0, st, h->m, h->n, A, h->pack);
+    return hipGetLastError();
+}
+
+template <int MP, int NP>
+static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
+                               double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
+                               hipStream_t st) {
+    plan<MP, NP>(h, B);
+    hipError_t e = hipFuncSetAttribute((const void*)ipm_solve_kernel<MP, NP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ipm_solve_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+                       h->pack, b, c, x, y, z, pobj, dobj, status, iters, o);
+    return hipGetLastError();
+}
+
+template <int MP, int NP>
+static hipError_t launch_newton(pycllp_hip_dense* h, long B, const double* x, const double* z, const double* y,
+                                const double* b, const double* c, double mu, double* dy, int* nref, DevOpts o,
+                                hipStream_t st) {
+    plan<MP, NP>(h, B);
+    hipError_t e = hipFuncSetAttribute((const void*)newton_kernel<MP, NP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((newton_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+                       h->pack, x, z, y, b, c, mu, dy, nref, o);
+    return hipGetLastError();
+}
+
+struct Variant {
+    int mp, np, apack;
+    pack_launch_fn pack;
+    solve_launch_fn solve;
+    newton_launch_fn newton;
+};
+
+#define VARIANT(MP, NP) \
+    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_newton<MP, NP> }
+
+// ordered by cost: the first variant that covers (m, n) is used
+static const Variant kVariants[] = {
+    VARIANT(16, 32), VARIANT(16, 48), VARIANT(16, 64), VARIANT(32, 64),
+    VARIANT(32, 96), VARIANT(32, 128),
+};
+static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+static DevOpts to_dev(const pycllp_hip_opts* opts) {
+    pycllp_hip_opts d;
+    pycllp_hip_default_opts(&d);
+    if (opts) d = *opts;
+    DevOpts o;
+    o.eps = d.eps; o.delta = d.delta; o.r = d.r; o.pivot_floor = d.pivot_floor; o.refine_tol = d.refine_tol;
+    o.max_iter = d.max_iter; o.max_refine = d.max_refine; o.flags = d.flags;
+    return o;
+}
+
+extern "C" {
+
+int pycllp_hip_abi_version(void) { return PYCLLP_HIP_ABI_VERSION; }
+
+const char* pycllp_hip_last_error(void) { return g_err; }
+
+void pycllp_hip_default_opts(pycllp_hip_opts* o) {
+    if (!o) return;
+    o->eps = 1e-10;
+    o->delta = 0.02;
+    o->r = 0.9;
+    o->pivot_floor = 1e-6;
+    o->refine_tol = 1e-8;
+    o->max_iter = 200;
+    o->max_refine = 5;
+    o->flags = 0;
+    o->reserved = 0;
+}
+
+int pycllp_hip_dense_max_rows(void) { return 32; }
+int pycllp_hip_dense_max_cols(void) { return 128; }
+
+int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycllp_hip_dense** handle) {
+    if (!A_dev || !handle || m <= 0 || n <= 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_init: bad argument");
+    int vi = -1;
+    for (int i = 0; i < kNumVariants; i++)
+        if (m <= kVariants[i].mp && n <= kVariants[i].np) { vi = i; break; }
+    if (vi < 0) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_dense_init: (m=%d, n=%d) exceeds the compiled kernels (m<=32, n<=128)", m, n);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    pycllp_hip_dense* h = (pycllp_hip_dense*)calloc(1, sizeof(pycllp_hip_dense));
+    if (!h) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_dense_init: out of host memory");
+    h->m = m; h->n = n; h->variant = vi; h->mp = kVariants[vi].mp; h->np = kVariants[vi].np;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { free(h); return set_err((int)e, "hipGetDeviceProperties"); }
+    h->num_cu = prop.multiProcessorCount;
+    h->max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (h->max_lds > 160 * 1024) h->max_lds = 160 * 1024;
+    if (h->max_lds <= 0) h->max_lds = 64 * 1024;
+    e = hipMalloc((void**)&h->pack, sizeof(double) * kVariants[vi].apack);
+    if (e != hipSuccess) { free(h); return set_err((int)e, "hipMalloc(pack)"); }
+    hipStream_t st = (hipStream_t)stream;
+    e = kVariants[vi].pack(h, A_dev, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "pack_A_kernel"); }
+    *handle = h;
+    return 0;
+}
+
+int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, const double* c_dev, double* x_dev,
+                           double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
+                           int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
+    if (!h || !b_dev || !c_dev || !x_dev || !status_dev || B < 0)
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: bad argument");
+    if (B == 0) return 0;
+    DevOpts o = to_dev(opts);
+    if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
+    hipError_t e = kVariants[h->variant].solve(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev,
+                                               status_dev, iters_dev, o, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err((int)e, "ipm_solve_kernel launch");
+    return 0;
+}
+
+int pycllp_hip_dense_newton(pycllp_hip_dense* h, long B, const double* x_dev, const double* z_dev,
+                            const double* y_dev, const double* b_dev, const double* c_dev, double mu, double* dy_dev,
+                            int* nrefine_dev, const pycllp_hip_opts* opts, void* stream) {
+    if (!h || !x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev || B < 0)
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_newton: bad argument");
+    if (B == 0) return 0;
+    DevOpts o = to_dev(opts);
+    hipError_t e = kVariants[h->variant].newton(h, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o,
+                                                (hipStream_t)stream);
+    if (e != hipSuccess) return set_err((int)e, "newton_kernel launch");
+    return 0;
+}
+
+int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* block, int* lds_bytes, int* m_pad,
+                                 int* n_pad) {
+    if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_launch_info: bad argument");
+    if (grid) *grid = h->grid;
+    if (block) *block = h->block;
+    if (lds_bytes) *lds_bytes = h->lds;
+    if (m_pad) *m_pad = h->mp;
+    if (n_pad) *n_pad = h->np;
+    return 0;
+}
+
+void pycllp_hip_dense_free(pycllp_hip_dense* h) {
+    if (!h) return;
+    if (h->pack) (void)hipFree(h->pack);
+    free(h);
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""HIP host for the batched dense primal-normal interior-point solver.
+
+Mirrors the contract of the reference's OpenCL host ``ClDensePrimalNormalSolver``
+(``pycllp/solvers/cl.py:12-124``): the constructor takes optional device handles, ``init(lp)`` captures
+the shared constraint matrix once, ``solve(lp)`` consumes the LP's current ``b``/``c`` and leaves
+``self.x [nproblems, ncols]`` and ``self.status [nproblems]`` as attributes.  Differences, all
+supersets: ``solve`` also returns ``self.status`` (as the reference's CPU solvers do,
+``pycllp/solvers/normal_eqns.py:33``) and sets ``y, z, primal_obj, dual_obj, iters``.
+
+PyTorch is plumbing only (device memory, streams); the compute is ``csrc/libpycllp_hip.so``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import BaseSolver
+from .. import _native
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("pycllp_amd: no ROCm device visible -- the HIP solvers have no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+class HipDensePrimalNormalSolver(BaseSolver):
+    """Drop-in for ``cl_dense_primal_normal`` on MI355X.  The LP must be in equality form
+    (callers use ``StandardLP.to_equality_form()`` first, as for the OpenCL solver)."""
+    name = 'hip_dense_primal_normal'
+
+    def __init__(self, device=None, stream=None, keep_on_device=False, **options):
+        super(HipDensePrimalNormalSolver, self).__init__()
+        self.device = device
+        self.stream = stream
+        self.keep_on_device = keep_on_device
+        self.options = dict(options)
+        _native.default_opts(**self.options) if options else None  # validate names early
+        self._handle = None
+        self.buffers = {}
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _stream_ptr(self):
+        st = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(st.cuda_stream)
+
+    def _dev(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=torch.float64).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=self.device)
+
+    @staticmethod
+    def _ptr(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+    def _free(self):
+        if self._handle is not None:
+            _native.lib().pycllp_hip_dense_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    # -- plugin API ------------------------------------------------------------------------------
+    def init(self, lp, verbose=0):
+        """Densify and upload A once (``pycllp/solvers/cl.py:39,46``)."""
+        self.device = _require_gpu(self.device)
+        L = _native.lib()
+        m, n = int(lp.nrows), int(lp.ncols)
+        A = lp.A.todense() if hasattr(lp.A, "todense") else lp.A
+        A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        if A.shape != (m, n):
+            raise ValueError("A has shape %r, expected (%d, %d)" % (A.shape, m, n))
+        if verbose > 0:
+            print("Initializing HipDensePrimalNormalSolver (m=%d, n=%d) on %s" % (m, n, self.device))
+        self._free()
+        with torch.cuda.device(self.device):
+            A_dev = self._dev(A)
+            h = ctypes.c_void_p()
+            _native.check(L.pycllp_hip_dense_init(m, n, self._ptr(A_dev), self._stream_ptr(), ctypes.byref(h)),
+                          "pycllp_hip_dense_init")
+        self._handle = h
+        self.m, self.n = m, n
+        self.buffers = {}
+
+    def _buffers(self, B):
+        if self.buffers.get("B") != B:
+            dev, f64, i32 = self.device, torch.float64, torch.int32
+            self.buffers = dict(
+                B=B,
+                x=torch.empty((B, self.n), dtype=f64, device=dev), z=torch.empty((B, self.n), dtype=f64, device=dev),
+                y=torch.empty((B, self.m), dtype=f64, device=dev),
+                pobj=torch.empty(B, dtype=f64, device=dev), dobj=torch.empty(B, dtype=f64, device=dev),
+                status=torch.empty(B, dtype=i32, device=dev), iters=torch.empty(B, dtype=i32, device=dev))
+        return self.buffers
+
+    def solve_device(self, b, c, warm_start=False, **options):
+        """Device-resident entry: b [B,m], c [B,n] (torch CUDA or numpy) -> dict of CUDA tensors.
+        Asynchronous on the solver's stream."""
+        if self._handle is None:
+            raise RuntimeError("solve() called before init()")
+        b = self._dev(b); c = self._dev(c)
+        if b.ndim != 2 or c.ndim != 2 or b.shape[1] != self.m or c.shape[1] != self.n or b.shape[0] != c.shape[0]:
+            raise ValueError("b must be [B,%d] and c [B,%d] with equal B; got %r and %r"
+                             % (self.m, self.n, tuple(b.shape), tuple(c.shape)))
+        B = int(b.shape[0])
+        buf = self._buffers(B)
+        opts = dict(self.options); opts.update(options)
+        if warm_start:
+            opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
+        o = _native.default_opts(**opts)
+        with torch.cuda.device(self.device):
+            _native.check(_native.lib().pycllp_hip_dense_solve(
+                self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
+                self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
+                self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_dense_solve")
+        self._keepalive = (b, c)
+        return buf
+
+    def solve(self, lp, verbose=0):
+        """Solve every problem of ``lp`` (current ``lp.b``, ``lp.c``); results in attributes."""
+        if int(lp.nrows) != self.m or int(lp.ncols) != self.n:
+            raise ValueError("LP shape changed since init(): (%d,%d) vs (%d,%d)" % (lp.nrows, lp.ncols, self.m, self.n))
+        if verbose > 0:
+            print("Solving %d LPs with HipDensePrimalNormalSolver..." % lp.nproblems)
+        buf = self.solve_device(lp.b, lp.c)
+        torch.cuda.synchronize(self.device)
+        f = np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)
+        if self.keep_on_device:
+            self.x, self.y, self.z = buf["x"], buf["y"], buf["z"]
+            self.status, self.iters = buf["status"], buf["iters"]
+            ft = torch.as_tensor(np.broadcast_to(f, (buf["B"],)).copy(), device=self.device)
+            self.primal_obj, self.dual_obj = buf["pobj"] + ft, buf["dobj"] + ft
+        else:
+            self.x = buf["x"].cpu().numpy(); self.y = buf["y"].cpu().numpy(); self.z = buf["z"].cpu().numpy()
+            self.status = buf["status"].cpu().numpy(); self.iters = buf["iters"].cpu().numpy()
+            # objective offset f is added when reporting (as pycllp/solvers/pathfollowing.py:113-114)
+            self.primal_obj = buf["pobj"].cpu().numpy() + f
+            self.dual_obj = buf["dobj"].cpu().numpy() + f
+        if verbose > 0:
+            print("Solve complete.")
+        return self.status
+
+    def newton_step(self, x, z, y, b, c, mu, **options):
+        """Stand-alone Newton step dy for B states (the reference's ``solve_primal_normal`` kernel,
+        ``pycllp/cl/ldl.cl:602-653``, as launched by its ``tests/test_ldl.py:219-273``)."""
+        if self._handle is None:
+            raise RuntimeError("newton_step() called before init()")
+        x, z, y, b, c = [self._dev(np.atleast_2d(v) if not isinstance(v, torch.Tensor) else v) for v in (x, z, y, b, c)]
+        B = int(x.shape[0])
+        dy = torch.empty((B, self.m), dtype=torch.float64, device=self.device)
+        nref = torch.empty(B, dtype=torch.int32, device=self.device)
+        opts = dict(self.options); opts.update(options)
+        o = _native.default_opts(**opts)
+        with torch.cuda.device(self.device):
+            _native.check(_native.lib().pycllp_hip_dense_newton(
+                self._handle, B, self._ptr(x), self._ptr(z), self._ptr(y), self._ptr(b), self._ptr(c), float(mu),
+                self._ptr(dy), self._ptr(nref), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_dense_newton")
+        torch.cuda.synchronize(self.device)
+        self.nrefine = nref.cpu().numpy()
+        return dy.cpu().numpy()
+
+    def launch_info(self):
+        vals = [ctypes.c_int() for _ in range(5)]
+        _native.check(_native.lib().pycllp_hip_dense_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
+                      "pycllp_hip_dense_launch_info")
+        return dict(zip(("grid", "block", "lds_bytes", "m_pad", "n_pad"), [v.value for v in vals]))
