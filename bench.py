@@ -1,0 +1,214 @@
+#!/usr/bin/env python
+"""bench.py -- LPs solved/sec on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (HipDensePrimalNormalSolver.solve_device -> pycllp_hip_dense_solve) over one
+batch of synthetic LPs that is already resident in HBM, followed -- for N > 1 -- by the final result gather to
+rank 0 (RCCL).  Workload per GPU: 65 536 random dense LPs, StandardLP (m=32, n=64) -> equality form N=96, fp64
+(BASELINE.json configs[2]; with 8 GPUs this is configs[3], 524 288 LPs).  Weak scaling: per-GPU work is fixed.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the solve kernel against the FP64 FMA/MFMA peak (the path is
+compute bound: ~1500 flop per compulsory HBM byte) and also reports the algorithmic HBM rate;
+`cpu_baseline` is the reference's own CPU solver (pycllp/ipo.py -> ipo/hsd.c, built from the reference sources
+into oracle/_ref) timed on one host core on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M, N_STD, B_PER_GPU = 32, 64, 65536
+PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (datasheet)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md)
+
+
+def flops_per_lp(m, N, iters, refine=0.0):
+    """F_alg = I*[m(m+1)N + 8mN + m^3/3 + 4m^2(1+r) + 14N + 3m]."""
+    return iters * (m * (m + 1) * N + 8 * m * N + m ** 3 / 3.0 + 4 * m * m * (1 + refine) + 14 * N + 3 * m)
+
+
+def bytes_per_lp(m, N):
+    """Compulsory HBM traffic of the fused solve: b, c in; x, y, z out; objectives, status, iters."""
+    return 8 * (m + N) + 8 * (N + m) + 8 * N + 16 + 8
+
+
+def cpu_baseline(seconds=12.0):
+    """Reference CPU solver (oracle/_ref: ipo.py's hsd.c) on the first LPs of the same batch, 1 core."""
+    from oracle import hsd_ref
+    from pycllp_amd import problems
+    if not hsd_ref.available():
+        from oracle import port
+        A, b, c = problems.random_dense_arrays(M, N_STD, 2048, seed=0)
+        Ae, be, ce = problems.equality_arrays(A, b, c)
+        t = time.perf_counter(); port.dense_solve(Ae, be, ce, nthreads=1); dt = time.perf_counter() - t
+        return {"value": 2048 / dt, "unit": "LPs/s", "cores": 1, "kind": "port",
+                "sample": "first 2048 LPs of the workload, oracle/ipm_dense_ref.c single thread"}
+    nmax = 16384
+    A, b, c = problems.random_dense_arrays(M, N_STD, nmax, seed=0)
+    hsd_ref.solve_standard(A, b[:8], c[:8])   # warm the library
+    done, t0 = 0, time.perf_counter()
+    chunk = 256
+    while done < nmax and time.perf_counter() - t0 < seconds:
+        r = hsd_ref.solve_standard(A, b[done:done + chunk], c[done:done + chunk])
+        assert (r["status"] == 0).all()
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "LPs/s", "cores": 1, "kind": "reference",
+            "sample": "first %d LPs of the workload through oracle/_ref (reference ipo/hsd.c), %.1f s, single thread "
+                      "(the C solver keeps global state: not thread-safe)" % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pycllp_amd import problems
+    from pycllp_amd.lp import SparseMatrix, EqualityLP
+    from pycllp_amd.solvers import solver_registry
+    from pycllp_amd.dist import gather_batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    B = args.batch
+    A, b, c = problems.random_dense_arrays(M, N_STD, B, seed=0, shard=rank)
+    Ae, be, ce = problems.equality_arrays(A, b, c)
+    Nn = Ae.shape[1]
+    lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
+    solver = solver_registry["hip_dense_primal_normal"](device=dev)
+    lp.init(solver)
+    bd = torch.as_tensor(be, device=dev)
+    cd = torch.as_tensor(ce, device=dev)
+    sizes = [B] * world
+    fields = ("pobj", "dobj", "status", "iters", "x", "y")
+
+    def step():
+        buf = solver.solve_device(bd, cd)
+        if world > 1:
+            return buf, {k: gather_batch(buf[k], sizes, dst=0) for k in fields}
+        return buf, None
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        buf = solver.solve_device(bd, cd)          # the dominant kernel, on torch's current stream
+        ev[k][1].record()
+        if world > 1:
+            gathered = {f: gather_batch(buf[f], sizes, dst=0) for f in fields}
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+    status = buf["status"].cpu().numpy()
+    iters = buf["iters"].cpu().numpy()
+    pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
+    ok_local = int((status == 0).sum())
+    gap = float(np.max(np.abs(pobj - dobj) / np.maximum(1.0, np.abs(pobj))))
+    if world > 1:
+        agg = torch.tensor([ok_local, float(iters.sum())], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        ok_total, iters_mean = int(agg[0].item()), float(agg[1].item()) / (B * world)
+        if rank == 0:
+            assert gathered["x"].shape == (B * world, Nn) and gathered["status"].shape == (B * world,)
+    else:
+        ok_total, iters_mean = ok_local, float(iters.mean())
+
+    if rank == 0:
+        # parity on the committed golden LPs (outside the timed region)
+        parity = None
+        gpath = os.path.join(ROOT, "tests", "golden", "config_32x64.npz")
+        if os.path.exists(gpath):
+            g = np.load(gpath)
+            A2, b2, c2 = problems.random_dense_arrays(M, N_STD, int(g["nobj"]), seed=0)
+            _, b2e, c2e = problems.equality_arrays(A2, b2, c2)
+            r = solver.solve_device(b2e, c2e)
+            torch.cuda.synchronize(dev)
+            ep = np.abs(r["pobj"].cpu().numpy() - g["pobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+            ed = np.abs(r["dobj"].cpu().numpy() - g["dobj"]) / np.maximum(1.0, np.abs(g["dobj"]))
+            parity = {"golden_lps": int(g["nobj"]), "max_rel_err_primal_obj": float(ep.max()),
+                      "max_rel_err_dual_obj": float(ed.max()), "tolerance": 1e-8,
+                      "source": "reference ipo.py (hsd.c) via tests/golden/config_32x64.npz"}
+        total = B * world * args.steps
+        value = total / elapsed
+        f_lp = flops_per_lp(M, Nn, iters_mean)
+        tflops = f_lp * B / (kern_ms * 1e-3) / 1e12
+        gbs = bytes_per_lp(M, Nn) * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        info = solver.launch_info()
+        out = {
+            "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
+                                   "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
+                                   % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else ""),
+                       "lps_per_gpu": B, "lps_total": B * world, "m": M, "n": N_STD, "N_equality": Nn,
+                       "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world,
+                       "kernel": "ipm_solve_kernel<%d,%d> grid %d x block %d, %d B LDS"
+                                 % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},
+            "solved_optimal": ok_total, "mean_ipm_iterations": iters_mean, "max_rel_duality_gap_rank0": gap,
+            "parity": parity,
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "flop_per_lp": f_lp,
+                         "note": "FP64 FMA/MFMA peak; algorithmic flops of SURVEY 8d with the measured mean "
+                                 "iteration count, refinement passes counted as 0",
+                         "hbm_algorithmic": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                             "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": bytes_per_lp(M, Nn)}},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

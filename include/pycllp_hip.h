@@ -57,7 +57,8 @@ typedef struct pycllp_hip_opts {
     double delta;       /* centering parameter DELTA, default 0.02 (primal_normal.cl:10)     */
     double r;           /* step fraction R, default 0.9 (primal_normal.cl:11)                */
     double pivot_floor; /* LDL' diagonal floor, default 1e-6 (primal_normal.cl:275)          */
-    double refine_tol;  /* refinement tolerance, default 1e-8 (ldl.cl:645)                   */
+    double refine_tol;  /* refinement tolerance on max|b-Ax-A dx|, relative to 1+|b|, default
+                           1e-11 (reference: 1e-8 absolute on rhs-M dy, ldl.cl:645)          */
     int max_iter;       /* default 200 (primal_normal.cl:9)                                  */
     int max_refine;     /* default 5 (ldl.cl:645)                                            */
     int flags;          /* PYCLLP_FLAG_*                                                     */

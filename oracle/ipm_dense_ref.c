@@ -24,7 +24,8 @@
  *   - centering DELTA=0.02, mu = delta*gamma/(n+m) (primal_normal.cl:10,272);
  *   - step: theta starts at 0 so the step is clamped to <=1 (primal_normal.cl:134,143);
  *   - beta = sqrt(max |diag M|) (ldl.cl:280-294);
- *   - refinement with |r|, "+=" update, <=5 passes, tol 1e-8 (ldl.cl:642-652,535);
+ *   - refinement: <=5 passes (ldl.cl:642-652) driven by max|residual|, but on the x-space form of the
+ *     residual and with a relative tolerance -- see newton_dy();
  *   - NaN guard -> status 3 (normal_eqns.py:85-87).
  *
  * Unlike the reference, M = A diag(x/z) A' is formed once per iteration instead of
@@ -43,7 +44,7 @@ typedef struct oracle_opts {
     double delta;       /* centering parameter DELTA   (primal_normal.cl:10)       */
     double r;           /* step fraction R             (primal_normal.cl:11)       */
     double pivot_floor; /* LDL' diagonal floor `delta` (primal_normal.cl:275)      */
-    double refine_tol;  /* refinement tolerance        (ldl.cl:645)                */
+    double refine_tol;  /* refinement tolerance, relative to 1+|b| (ldl.cl:645 is 1e-8 absolute) */
     int max_iter;       /* MAX_ITER                    (primal_normal.cl:9)        */
     int max_refine;     /* refinement passes           (ldl.cl:645)                */
     int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219) */
@@ -54,7 +55,7 @@ void oracle_default_opts(oracle_opts *o) {
     o->delta = 0.02;
     o->r = 0.9;
     o->pivot_floor = 1e-6;
-    o->refine_tol = 1e-8;
+    o->refine_tol = 1e-11;
     o->max_iter = 200;
     o->max_refine = 5;
     o->flags = 0;
@@ -159,13 +160,23 @@ static void factor(int m, const double *M, double *L, double *D, double floor_) 
 }
 
 /*
- * dy <- solution of  M dy = -(b - A x - A (x/z)(c - A'y + mu/x))   (ldl.cl:198-219, 602-653)
- * with <= max_refine refinement passes on the unperturbed M (ldl.cl:642-652).
- * Returns the number of refinement passes used.
+ * Newton step of the primal normal equations (ldl.cl:602-653):
+ *   M dy = -(b - A x - A (x/z)(c - A'y + mu/x)),   dx = (c - A'y + mu/x - A'dy) x/z   (primal_normal.cl:142)
+ * followed by <= max_refine passes of iterative refinement.  The reference refines on r = rhs - M dy with
+ * M re-formed from x/z (ldl.cl:577-599, 642-652); in floating point that residual cannot fall below
+ * eps*|M|*|dy| (|M| ~ 1/mu), which is what stalls the reference's primal feasibility near convergence
+ * (SURVEY section 7 hard part 1).  The restatement refines the SAME equation in x-space instead:
+ *   e = (b - A x) - A dx ;  M eta = e ;  dx += (x/z) A'eta ;  dy -= eta
+ * (mathematically r == e), stopping when max|e| <= refine_tol * (1 + |b|).  dx is accumulated, so the
+ * rounding error of every pass scales with the size of that pass's correction.
+ * Outputs: wk->dy, wk->w (= dx).  Returns the number of refinement passes used.
  */
 static int newton_dy(int m, int N, const double *A, const double *x, const double *z, const double *y,
                      const double *b, const double *c, double mu, const oracle_opts *o, work *wk) {
-    double *d = wk->d, *t = wk->t;
+    double *d = wk->d, *t = wk->t, *dx = wk->w;
+    double nb = 0.0;
+    for (int i = 0; i < m; i++) nb += b[i] * b[i];
+    const double etol = o->refine_tol * (1.0 + sqrt(nb));
     for (int k = 0; k < N; k++) {
         double aty = 0.0;
         for (int i = 0; i < m; i++) aty += A[i * N + k] * y[i];
@@ -175,27 +186,38 @@ static int newton_dy(int m, int N, const double *A, const double *x, const doubl
     gram(m, N, A, d, wk->M);
     factor(m, wk->M, wk->L, wk->D, o->pivot_floor);
     for (int i = 0; i < m; i++) {
-        double rhs = b[i];
+        double rho = b[i], adt = 0.0;
         for (int k = 0; k < N; k++) {
-            rhs += -A[i * N + k] * x[k];
-            rhs += -A[i * N + k] * d[k] * t[k];
+            rho -= A[i * N + k] * x[k];
+            adt += A[i * N + k] * d[k] * t[k];
         }
-        wk->rhs[i] = -rhs;
-        wk->S[i] = -rhs;
-        wk->dy[i] = 0.0;
+        wk->rho[i] = rho;
+        wk->S[i] = adt - rho; /* = -(b - Ax - A d t), ldl.cl:198-219 */
+    }
+    oracle_forward_backward(m, wk->L, wk->D, wk->S);
+    for (int i = 0; i < m; i++) wk->dy[i] = wk->S[i];
+    for (int k = 0; k < N; k++) {
+        double atdy = 0.0;
+        for (int i = 0; i < m; i++) atdy += A[i * N + k] * wk->dy[i];
+        dx[k] = (t[k] - atdy) * d[k];
     }
     int nref = 0;
     for (;;) {
-        oracle_forward_backward(m, wk->L, wk->D, wk->S);
-        for (int i = 0; i < m; i++) wk->dy[i] += wk->S[i];
-        double maxr = 0.0;
+        double maxe = 0.0;
         for (int i = 0; i < m; i++) {
-            double r = wk->rhs[i];
-            for (int j = 0; j < m; j++) r -= wk->M[i * m + j] * wk->dy[j];
-            wk->S[i] = r;
-            maxr = fmax(maxr, fabs(r));
+            double adx = 0.0;
+            for (int k = 0; k < N; k++) adx += A[i * N + k] * dx[k];
+            wk->S[i] = wk->rho[i] - adx;
+            maxe = fmax(maxe, fabs(wk->S[i]));
         }
-        if (!(maxr > o->refine_tol) || nref >= o->max_refine) break;
+        if (!(maxe > etol) || nref >= o->max_refine) break;
+        oracle_forward_backward(m, wk->L, wk->D, wk->S);
+        for (int i = 0; i < m; i++) wk->dy[i] -= wk->S[i];
+        for (int k = 0; k < N; k++) {
+            double ate = 0.0;
+            for (int i = 0; i < m; i++) ate += A[i * N + k] * wk->S[i];
+            dx[k] += d[k] * ate;
+        }
         nref++;
     }
     return nref;
@@ -273,13 +295,10 @@ static int ipm_one(int m, int N, const double *A, const double *b, const double 
         for (int i = 0; i < m; i++) if (!isfinite(dy[i])) bad = 1;
         if (bad) { stat = 3; break; }
 
-        /* primal_normal_step, primal_normal.cl:122-156 */
+        /* primal_normal_step, primal_normal.cl:122-156 (dx comes refined from newton_dy) */
         double theta = 0.0;
         double *dx = wk->w, *dz = wk->sigma;
         for (int j = 0; j < N; j++) {
-            double aty = 0.0, atdy = 0.0;
-            for (int i = 0; i < m; i++) { aty += A[i * N + j] * y[i]; atdy += A[i * N + j] * dy[i]; }
-            dx[j] = (c[j] - aty + mu / x[j] - atdy) * x[j] / z[j];
             dz[j] = (mu - z[j] * dx[j]) / x[j] - z[j];
             theta = fmax(theta, fmax(-dz[j] / z[j], -dx[j] / x[j]));
         }

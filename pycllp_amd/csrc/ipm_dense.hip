@@ -253,19 +253,43 @@ struct Wave {
         return s;
     }
 
-    // M*v with row ri of M in Mrow, v in lane=row layout
-    __device__ __forceinline__ double M_times(const double (&Mrow)[MP], double v) const {
-        double acc = 0.0;
+    // u = A * vq  (vq per column -> lane=row layout) through the MFMA-order image: the k-layout copy of vq is
+    // staged in the wave's kx slot, every lane accumulates its 4-column slice, two shuffles fold the 4 lane groups
+    __device__ __forceinline__ double A_times(const double (&vq)[NC]) const {
 #pragma unroll
-        for (int k = 0; k < MP; k++) acc = fma(Mrow[k], readlane_d(v, k), acc);
-        return acc;
+        for (int q = 0; q < NC; q++) {
+            const int j = lane + 64 * q;
+            if (j < NP) kx[G::kpos(j)] = (j < n) ? vq[q] : 0.0;
+        }
+        wave_lds_sync();
+        const double* px = kx + (lane >> 4) * KS;
+        double acc[JB];
+#pragma unroll
+        for (int J = 0; J < JB; J++) acc[J] = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const double xk = px[s];
+#pragma unroll
+            for (int J = 0; J < JB; J++) acc[J] = fma(Amf[(J * KS + s) * 64 + lane], xk, acc[J]);
+        }
+#pragma unroll
+        for (int J = 0; J < JB; J++) {
+            acc[J] += __shfl_xor(acc[J], 16, WAVE);
+            acc[J] += __shfl_xor(acc[J], 32, WAVE);
+        }
+        wave_lds_sync();
+        if (JB == 1) return acc[0];
+        return ((ri >> 4) & 1) ? acc[JB - 1] : acc[0];
     }
 
-    // Newton step dy of the primal normal equations (ldl.cl:602-653) given x, z, c, v=A'y, b, mu.
-    // Returns dy (lane=row); outputs d, t (per column), rho and the refinement count.
+    // Newton step of the primal normal equations (ldl.cl:602-653) given x, z, c, v=A'y, b, mu:
+    //   M dy = A d t - rho,  dx = d (t - A'dy),  then <= max_refine passes of x-space refinement
+    //   e = rho - A dx ; M eta = e ; dx += d A'eta ; dy -= eta      (see oracle/ipm_dense_ref.c newton_dy)
+    // Returns dy (lane=row); outputs dx, wv = A'dy (per column), rho and the refinement count.
     __device__ __forceinline__ double newton(const double (&x)[NC], const double (&z)[NC], const double (&c)[NC],
-                                             const double (&v)[NC], double b, double mu, const DevOpts& o,
-                                             double (&d)[NC], double (&t)[NC], double& rho, int& nref) const {
+                                             const double (&v)[NC], double b, double mu, double etol, const DevOpts& o,
+                                             double (&dx)[NC], double (&wv)[NC], double& rho, int& nref) const {
+        double d[NC], t[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             const int j = lane + 64 * q;
@@ -285,34 +309,41 @@ struct Wave {
         rho = b - Ax;                       // primal_normal.cl:30-48
         const double rhs = Adt - rho;       // -(b - Ax - A d t), ldl.cl:198-219
         wave_lds_sync();
-        // pull row ri of M out of the slab; padded rows become identity rows
-        double W[MP], Mrow[MP];
+        double rdiag;
         {
+            // pull row ri of M out of the slab; padded rows become identity rows
+            double W[MP];
             const double* row = slab + ri * MS;
 #pragma unroll
             for (int k = 0; k < MP; k++) W[k] = row[k];
-        }
-        double diag = slab[ri * MS + ri];
-        if (ri >= m) {
+            double diag = slab[ri * MS + ri];
+            if (ri >= m) {
 #pragma unroll
-            for (int k = 0; k < MP; k++) W[k] = (k == ri) ? 1.0 : W[k];
-            diag = 0.0;
+                for (int k = 0; k < MP; k++) W[k] = (k == ri) ? 1.0 : W[k];
+                diag = 0.0;
+            }
+            const double beta2 = wave_max(fabs(diag));  // beta^2 = max |M_ii|, ldl.cl:280-294
+            wave_lds_sync();
+            factor(W, beta2, o.pivot_floor, rdiag);
         }
+        double dy = fwd_back(rhs, rdiag);
+        At_times(dy, wv);
 #pragma unroll
-        for (int k = 0; k < MP; k++) Mrow[k] = W[k];
-        const double beta2 = wave_max(fabs(diag));  // beta^2 = max |M_ii|, ldl.cl:280-294
-        wave_lds_sync();
-        double rdiag;
-        factor(W, beta2, o.pivot_floor, rdiag);
-        // solve + refinement on the unperturbed M (ldl.cl:632-652)
-        double dy = 0.0, s = rhs;
+        for (int q = 0; q < NC; q++) dx[q] = (t[q] - wv[q]) * d[q];   // primal_normal.cl:142
         nref = 0;
         for (;;) {
-            s = fwd_back(s, rdiag);
-            dy += s;
-            s = rhs - M_times(Mrow, dy);
-            const double maxr = wave_max(fabs(s));
-            if (!(maxr > o.refine_tol) || nref >= o.max_refine) break;
+            const double e = rho - A_times(dx);
+            const double maxe = wave_max(fabs(e));
+            if (!(maxe > etol) || nref >= o.max_refine) break;
+            const double eta = fwd_back(e, rdiag);
+            double w2[NC];
+            At_times(eta, w2);
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                dx[q] = fma(d[q], w2[q], dx[q]);
+                wv[q] -= w2[q];
+            }
+            dy -= eta;
             nref++;
         }
         return dy;
@@ -374,6 +405,7 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
         nc2 = wave_sum(nc2);
         const double tol_r = o.eps * (1.0 + sqrt(nb2));
         const double tol_s = o.eps * (1.0 + sqrt(nc2));
+        const double etol = o.refine_tol * (1.0 + sqrt(nb2));
         double normr0 = 1e300, norms0 = 1e300;
         int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
         double po = 0.0, du = 0.0;
@@ -394,9 +426,9 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
             const double mu = o.delta * gam / (double)(n + m);  // primal_normal.cl:272
 
             // Newton step (also yields rho = b - Ax for the stop test of THIS point)
-            double d[NC], t[NC], rho;
+            double dx[NC], wv[NC], rho;
             int nref;
-            const double dy = w.newton(x, z, c, v, b, mu, o, d, t, rho, nref);
+            const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref);
             const double normr = sqrt(wave_sum((lane < MP) ? rho * rho : 0.0));
 
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
@@ -406,12 +438,10 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
             if (__any(!isfinite(dy))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
 
             // step (primal_normal.cl:122-156)
-            double wv[NC], dx[NC], dz[NC];
-            w.At_times(dy, wv);
+            double dz[NC];
             double th = 0.0;
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-                dx[q] = (t[q] - wv[q]) * d[q];
                 dz[q] = ok[q] ? (mu - z[q] * dx[q]) / x[q] - z[q] : 0.0;
                 if (ok[q]) th = fmax(th, fmax(-dz[q] / z[q], -dx[q] / x[q]));
             }
@@ -476,7 +506,7 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
     w.kdt = w.kd + NP;
     const int lane = w.lane, ri = w.ri;
     for (long lp = (long)blockIdx.x * wpb + wave; lp < B; lp += (long)gridDim.x * wpb) {
-        double x[NC], z[NC], c[NC], v[NC], d[NC], t[NC];
+        double x[NC], z[NC], c[NC], v[NC], dx[NC], wv[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             const int j = lane + 64 * q;
@@ -488,9 +518,10 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
         const double b = (ri < m) ? bg[lp * m + ri] : 0.0;
         const double y = (ri < m) ? yg[lp * m + ri] : 0.0;
         w.At_times(y, v);
+        const double etol = o.refine_tol * (1.0 + sqrt(wave_sum((lane < MP) ? b * b : 0.0)));
         double rho;
         int nref;
-        const double dy = w.newton(x, z, c, v, b, mu, o, d, t, rho, nref);
+        const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref);
         if (lane < MP && ri < m) dyg[lp * m + ri] = dy;
         if (nrefg && lane == 0) nrefg[lp] = nref;
     }
@@ -621,7 +652,7 @@ void pycllp_hip_default_opts(pycllp_hip_opts* o) {
     o->delta = 0.02;
     o->r = 0.9;
     o->pivot_floor = 1e-6;
-    o->refine_tol = 1e-8;
+    o->refine_tol = 1e-11;
     o->max_iter = 200;
     o->max_refine = 5;
     o->flags = 0;
@@ -665,9 +696,10 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
 int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, const double* c_dev, double* x_dev,
                            double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
                            int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
-    if (!h || !b_dev || !c_dev || !x_dev || !status_dev || B < 0)
+    if (!h || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: bad argument");
+    if (B == 0) return 0;  // empty batch: nothing to do (pointers may be NULL)
+    if (!b_dev || !c_dev || !x_dev || !status_dev)
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: bad argument");
-    if (B == 0) return 0;
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
@@ -680,9 +712,10 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
 int pycllp_hip_dense_newton(pycllp_hip_dense* h, long B, const double* x_dev, const double* z_dev,
                             const double* y_dev, const double* b_dev, const double* c_dev, double mu, double* dy_dev,
                             int* nrefine_dev, const pycllp_hip_opts* opts, void* stream) {
-    if (!h || !x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev || B < 0)
-        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_newton: bad argument");
+    if (!h || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_newton: bad argument");
     if (B == 0) return 0;
+    if (!x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev)
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_newton: bad argument");
     DevOpts o = to_dev(opts);
     hipError_t e = kVariants[h->variant].newton(h, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o,
                                                 (hipStream_t)stream);

@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz -- run HERE (this container), never on the GPU box.
+
+Golden OUTPUTS come from the reference's own CPU solver, `pycllp/ipo.py` -> `ipo/hsd.c` (Vanderbei's
+homogeneous self-dual IPM), compiled from the reference sources into oracle/_ref/libhsd_ref.so by
+oracle/Makefile and called exactly like the reference's wrapper does (oracle/hsd_ref.py).  INPUTS are the
+data of the reference's own tests (tests/vanderbei_problems.py, tests/test_simple.py, tests/helpers.py)
+and the SURVEY section 8d synthetic generator.  Only data is written: inputs + expected outputs.
+
+The reference's tests use GLPK as ground truth for random problems (tests/helpers.py:63-64,91-95); GLPK is
+absent here, so the HSD solver (the parity oracle BASELINE.json names) stands in for it.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import hsd_ref, port  # noqa: E402
+from pycllp_amd import problems  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def hsd(A, b, c):
+    r = hsd_ref.solve_standard(A, b, c)
+    return dict(x=r["x"], y=r["y"], pobj=r["pobj"], dobj=r["dobj"], status=r["status"])
+
+
+def textbook():
+    lp29, xopt29 = problems.vanderbei_2_9()
+    A, b, c = lp29.A.todense(), lp29.b, lp29.c
+    g = hsd(A, b, c)
+    lp210, xopt210 = problems.vanderbei_2_10()
+    np.savez(os.path.join(OUT, "vanderbei.npz"),
+             v29_A=A, v29_b=b, v29_c=c, v29_xopt=xopt29, v29_x=g["x"], v29_y=g["y"], v29_pobj=g["pobj"],
+             v29_dobj=g["dobj"], v29_status=g["status"],
+             v210_A=lp210.A.todense(), v210_b=lp210.b, v210_c=lp210.c, v210_xopt=xopt210)
+    print("vanderbei 2.9: HSD x", g["x"][0], "pobj", g["pobj"][0], "dobj", g["dobj"][0])
+
+
+def small_problem():
+    A, b, c = problems.small_problem_arrays()
+    g1 = hsd(A, b[None], c[None])
+    Ap, bb, cc = problems.parallel_small_problem_arrays(32)
+    g = hsd(Ap, bb, cc)
+    np.savez(os.path.join(OUT, "small_problem.npz"), A=A, b=b, c=c, x1=g1["x"], pobj1=g1["pobj"], dobj1=g1["dobj"],
+             bb=bb, cc=cc, x=g["x"], y=g["y"], pobj=g["pobj"], dobj=g["dobj"], status=g["status"])
+    print("small problem: x", g1["x"][0], "status x32", np.bincount(g["status"]))
+
+
+def helpers_random(m, n, density=1.0, nproblems=1):
+    """Input generator of the reference's tests/helpers.py:35-60 (np.random.seed(0), rows from
+    scipy.sparse.rand, b,c ~ U[0,1))."""
+    from scipy.sparse import rand
+    np.random.seed(0)
+    A = np.empty((m, n))
+    for i in range(m):
+        A[i, :] = rand(1, n, density=max(density, 3. / n)).todense()
+    b = np.random.rand(nproblems, m)
+    c = np.random.rand(nproblems, n)
+    return A, b, c
+
+
+def random_helpers():
+    out = {}
+    for (m, n) in ((10, 10), (20, 20)):
+        A, b, c = helpers_random(m, n)
+        g = hsd(A, b, c)
+        k = "r%dx%d_" % (m, n)
+        out.update({k + "A": A, k + "b": b, k + "c": c, k + "x": g["x"], k + "y": g["y"], k + "pobj": g["pobj"],
+                    k + "dobj": g["dobj"], k + "status": g["status"]})
+        print("helpers random (%d,%d): status" % (m, n), g["status"], "pobj", g["pobj"], "gap", g["pobj"] - g["dobj"])
+    np.savez(os.path.join(OUT, "random_helpers.npz"), **out)
+
+
+def baseline_config(m, n, nobj=4096, nfull=256):
+    """SURVEY 8d generator; inputs are regenerated from the seed by the tests (a checksum pins them)."""
+    A, b, c = problems.random_dense_arrays(m, n, nobj, seed=0)
+    g = hsd(A, b, c)
+    gap = np.abs(g["pobj"] - g["dobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+    np.savez_compressed(os.path.join(OUT, "config_%dx%d.npz" % (m, n)), m=m, n=n, seed=0, nobj=nobj,
+                        input_checksum=np.array([A.sum(), b.sum(), c.sum()]),
+                        pobj=g["pobj"], dobj=g["dobj"], status=g["status"].astype(np.int8),
+                        x=g["x"][:nfull], y=g["y"][:nfull])
+    print("config (%d,%d): %d LPs, status" % (m, n, nobj), np.bincount(g["status"]), "max internal gap", gap.max())
+
+
+def newton_states():
+    """(A, x, z, y, b, c, mu) -> dy by the known-answer formula of the reference's tests/test_ldl.py:196-216,
+    on (i) the input recipe of tests/test_ldl.py:226-238 (seed 123456) at kernel-sized shapes and (ii) states
+    harvested along an IPM trajectory (late iterations are ill conditioned: x/z spans many decades)."""
+    out = {}
+    for (m, n, nb) in ((16, 32, 32), (32, 64, 32), (20, 30, 32)):
+        np.random.seed(123456)
+        A = np.c_[np.random.rand(m, n), np.eye(m)]
+        x = np.random.rand(m + n, nb).T.copy(); z = np.random.rand(m + n, nb).T.copy()
+        y = np.random.rand(m, nb).T.copy(); b = np.random.rand(m, nb).T.copy()
+        c = np.r_[np.random.rand(n, nb), np.zeros((m, nb))].T.copy()
+        dy = np.stack([port.newton_step_known_answer(A, x[i], z[i], y[i], b[i], c[i], 1.0) for i in range(nb)])
+        k = "t%dx%d_" % (m, n)
+        out.update({k + "A": A, k + "x": x, k + "z": z, k + "y": y, k + "b": b, k + "c": c, k + "mu": 1.0, k + "dy": dy})
+    # trajectory states of config 3 LP 0..3 at iterations 5, 12, 18, 21 (numpy path following, delta/r of the CL kernel)
+    m, n = 32, 64
+    A0, b0, c0 = problems.random_dense_arrays(m, n, 4, seed=0)
+    A, b, c = problems.equality_arrays(A0, b0, c0)
+    N = n + m
+    xs, zs, ys, bs, cs, mus, dys = [], [], [], [], [], [], []
+    for p in range(4):
+        x = np.ones(N); z = np.ones(N); y = np.ones(m)
+        for it in range(22):
+            gamma = z @ x
+            mu = 0.02 * gamma / (N + m)
+            dy = port.newton_step_known_answer(A, x, z, y, b[p], c[p], mu)
+            if it in (5, 12, 18, 21):
+                xs.append(x.copy()); zs.append(z.copy()); ys.append(y.copy()); bs.append(b[p]); cs.append(c[p])
+                mus.append(mu); dys.append(dy)
+            d = x / z
+            dx = (c[p] - A.T @ y + mu / x - A.T @ dy) * d
+            dz = (mu - z * dx) / x - z
+            th = max(0.0, np.max(-dx / x), np.max(-dz / z))
+            th = min(0.9 / th, 1.0)
+            x += th * dx; z += th * dz; y += th * dy
+    out.update(traj_A=A, traj_x=np.array(xs), traj_z=np.array(zs), traj_y=np.array(ys), traj_b=np.array(bs),
+               traj_c=np.array(cs), traj_mu=np.array(mus), traj_dy=np.array(dys))
+    print("newton states: cond-ish spread x/z", [float(np.log10((a / b_).max() / (a / b_).min())) for a, b_ in zip(xs[:4], zs[:4])])
+    np.savez_compressed(os.path.join(OUT, "newton_states.npz"), **out)
+
+
+if __name__ == "__main__":
+    if not hsd_ref.available():
+        sys.exit("oracle/_ref/libhsd_ref.so missing: run `make -C oracle` in the container that has /root/reference")
+    os.makedirs(OUT, exist_ok=True)
+    textbook()
+    small_problem()
+    random_helpers()
+    newton_states()
+    baseline_config(16, 32)
+    baseline_config(32, 64)
