@@ -131,11 +131,16 @@ struct Wave {
     __device__ __forceinline__ void At_times(double u, double out[NC]) const {
 #pragma unroll
         for (int q = 0; q < NC; q++) out[q] = 0.0;
+        // chunks of 8 rows: bounded unrolling keeps the LDS loads the scheduler hoists (and the broadcast SGPRs) few
+#pragma unroll 1
+        for (int i0 = 0; i0 < MP; i0 += 8) {
 #pragma unroll
-        for (int i = 0; i < MP; i++) {
-            double ui = readlane_d(u, i);
+            for (int ii = 0; ii < 8; ii++) {
+                const int i = i0 + ii;
+                const double ui = readlane_d(u, i);
 #pragma unroll
-            for (int q = 0; q < NC; q++) out[q] = fma(Arm[i * G::NL + lane + 64 * q], ui, out[q]);
+                for (int q = 0; q < NC; q++) out[q] = fma(Arm[i * G::NL + lane + 64 * q], ui, out[q]);
+            }
         }
     }
 
@@ -155,22 +160,28 @@ struct Wave {
         const double* px = kx + g * KS;
         const double* pd = kd + g * KS;
         const double* pt = kdt + g * KS;
+        static_assert(KS % 2 == 0, "k-steps are processed in pairs");
+        constexpr int SC = (KS % 4 == 0) ? 4 : 2;   // k-steps per chunk (bounded unrolling: see At_times)
+#pragma unroll 1
+        for (int s0 = 0; s0 < KS; s0 += SC) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            double xk = px[s], dk = pd[s], tk = pt[s];
-            double a[JB], ad[JB];
+            for (int ss = 0; ss < SC; ss++) {
+                const int s = s0 + ss;
+                const double xk = px[s], dk = pd[s], tk = pt[s];
+                double a[JB], ad[JB];
 #pragma unroll
-            for (int J = 0; J < JB; J++) {
-                a[J] = Amf[(J * KS + s) * 64 + lane];
-                axp[J] = fma(a[J], xk, axp[J]);
-                adp[J] = fma(a[J], tk, adp[J]);
-                ad[J] = a[J] * dk;
+                for (int J = 0; J < JB; J++) {
+                    a[J] = Amf[(J * KS + s) * 64 + lane];
+                    axp[J] = fma(a[J], xk, axp[J]);
+                    adp[J] = fma(a[J], tk, adp[J]);
+                    ad[J] = a[J] * dk;
+                }
+#pragma unroll
+                for (int I = 0; I < JB; I++)
+#pragma unroll
+                    for (int J = 0; J <= I; J++)
+                        acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[I], a[J], acc[I][J], 0, 0, 0);
             }
-#pragma unroll
-            for (int I = 0; I < JB; I++)
-#pragma unroll
-                for (int J = 0; J <= I; J++)
-                    acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[I], a[J], acc[I][J], 0, 0, 0);
         }
         // accumulator (I,J), register r4: row 16I + (lane>>4) + 4*r4, col 16J + (lane&15)
         const int cc = lane & 15;
@@ -225,7 +236,12 @@ struct Wave {
                 wave_lds_sync();
                 const double* Lj = slab + j * MS;
 #pragma unroll
-                for (int k = j + 1; k < MP; k++) W[k] = fma(-u, Lj[k], W[k]);
+                for (int k = j + 1; k < MP; k++) {
+                    W[k] = fma(-u, Lj[k], W[k]);
+                    // pin the update to column j: otherwise LLVM sinks the FMA chains to the column that consumes
+                    // them (a left-looking sweep), keeps every broadcast L value alive and spills ~2 KB per lane
+                    asm volatile("" : "+v"(W[k]));
+                }
             }
         }
         wave_lds_sync();
@@ -234,21 +250,26 @@ struct Wave {
     // s <- (L D L')^-1 s  (ldl.cl:505-537), s in lane=row layout
     __device__ __forceinline__ double fwd_back(double s, double rdiag) const {
         // forward, column oriented: t_i -= L[i][k] t_k
+#pragma unroll 1
+        for (int k0 = 0; k0 < MP; k0 += 8) {
 #pragma unroll
-        for (int k = 0; k < MP - 1; k++) {
-            double tk = readlane_d(s, k);
-            s = fma(-slab[k * MS + ri], tk, s);
+            for (int kk = 0; kk < 8; kk++) {
+                const int k = k0 + kk;
+                const double tk = readlane_d(s, k);
+                s = fma(-slab[k * MS + ri], tk, s);   // row MP-1 of the slab is all zero: harmless last step
+            }
         }
         s *= rdiag;
         // backward, column oriented: s_j -= L[i][j] s_i for j < i; lane j owns row j of the slab
-        double Lt[MP];
         const double* row = slab + ri * MS;
+#pragma unroll 1
+        for (int i0 = MP - 8; i0 >= 0; i0 -= 8) {
 #pragma unroll
-        for (int i = 0; i < MP; i++) Lt[i] = row[i];
-#pragma unroll
-        for (int i = MP - 1; i >= 1; i--) {
-            double si = readlane_d(s, i);
-            s = fma(-Lt[i], si, s);
+            for (int ii = 7; ii >= 0; ii--) {
+                const int i = i0 + ii;
+                const double si = readlane_d(s, i);
+                s = fma(-row[i], si, s);              // row[i] = L[i][ri] for i > ri, 0 otherwise
+            }
         }
         return s;
     }
@@ -266,11 +287,15 @@ struct Wave {
         double acc[JB];
 #pragma unroll
         for (int J = 0; J < JB; J++) acc[J] = 0.0;
+        constexpr int SC = (KS % 4 == 0) ? 4 : 2;
+#pragma unroll 1
+        for (int s0 = 0; s0 < KS; s0 += SC) {
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const double xk = px[s];
+            for (int ss = 0; ss < SC; ss++) {
+                const double xk = px[s0 + ss];
 #pragma unroll
-            for (int J = 0; J < JB; J++) acc[J] = fma(Amf[(J * KS + s) * 64 + lane], xk, acc[J]);
+                for (int J = 0; J < JB; J++) acc[J] = fma(Amf[(J * KS + s0 + ss) * 64 + lane], xk, acc[J]);
+            }
         }
 #pragma unroll
         for (int J = 0; J < JB; J++) {
