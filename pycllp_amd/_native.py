@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpycllp_hip.so")
+# PYCLLP_HIP_LIB lets a developer point at a diagnostic build of the SAME library (tools/phase_profile.py)
+LIB_PATH = os.environ.get("PYCLLP_HIP_LIB") or os.path.join(_HERE, "csrc", "libpycllp_hip.so")
 
 # every symbol include/pycllp_hip.h declares (tests/test_abi.py checks the two stay in sync)
 EXPORTS = (

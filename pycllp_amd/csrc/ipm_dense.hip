@@ -44,6 +44,15 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
+// 1/a for a normal, positive a: v_rcp_f64 seed + two Newton steps (<= 1 ulp); skips the scaling/fix-up of an
+// IEEE division, which the LDL' pivots (floored at pivot_floor) never need
+__device__ __forceinline__ double fast_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(r, fma(-a, r, 1.0), r);
+    r = fma(r, fma(-a, r, 1.0), r);
+    return r;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -67,7 +76,27 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct DevOpts {
     double eps, delta, r, pivot_floor, refine_tol;
     int max_iter, max_refine, flags;
+    unsigned long long* prof;  // diagnostic build only (-DPYCLLP_PROFILE): per-wave phase cycle sums
 };
+
+// In-kernel phase stamps (diagnostic build only; the shipped library has no stamp executing).
+#ifdef PYCLLP_PROFILE
+#define NPHASE 10
+#define STAMP_DECL unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0}; \
+    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long t_now_; __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
+    t_acc_[i] += t_now_ - t_prev_; t_prev_ = t_now_; }
+#define STAMP_ARGS , unsigned long long& t_prev_, unsigned long long (&t_acc_)[NPHASE]
+#define STAMP_PASS , t_prev_, t_acc_
+#define STAMP_FLUSH(o, wid) if ((o).prof && lane == 0) { for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_]; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_ARGS
+#define STAMP_PASS
+#define STAMP_FLUSH(o, wid)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // compile-time geometry
@@ -228,20 +257,22 @@ struct Wave {
                 double theta = wave_max(below ? fabs(u) : 0.0);
                 aD = fmax(aD, theta * theta / beta2);
             }
-            const double rD = 1.0 / aD;
+            const double rD = fast_rcp(aD);
             const double l = below ? u * rD : 0.0;
             if (ri == j) rdiag = rD;
             slab[j * MS + ri] = l;  // lanes >= MP write the same value as their twin: benign
             if (j + 1 < MP) {
                 wave_lds_sync();
                 const double* Lj = slab + j * MS;
+                double lk[MP];
 #pragma unroll
-                for (int k = j + 1; k < MP; k++) {
-                    W[k] = fma(-u, Lj[k], W[k]);
-                    // pin the update to column j: otherwise LLVM sinks the FMA chains to the column that consumes
-                    // them (a left-looking sweep), keeps every broadcast L value alive and spills ~2 KB per lane
-                    asm volatile("" : "+v"(W[k]));
-                }
+                for (int k = j + 1; k < MP; k++) lk[k] = Lj[k];          // broadcast reads, batched
+#pragma unroll
+                for (int k = j + 1; k < MP; k++) W[k] = fma(-u, lk[k], W[k]);
+                // pin the update to column j: otherwise LLVM sinks the FMA chains to the column that consumes
+                // them (a left-looking sweep), keeps every broadcast L value alive and spills ~2 KB per lane
+#pragma unroll
+                for (int k = j + 1; k < MP; k++) asm volatile("" : "+v"(W[k]));
             }
         }
         wave_lds_sync();
@@ -313,7 +344,7 @@ struct Wave {
     // Returns dy (lane=row); outputs dx, wv = A'dy (per column), rho and the refinement count.
     __device__ __forceinline__ double newton(const double (&x)[NC], const double (&z)[NC], const double (&c)[NC],
                                              const double (&v)[NC], double b, double mu, double etol, const DevOpts& o,
-                                             double (&dx)[NC], double (&wv)[NC], double& rho, int& nref) const {
+                                             double (&dx)[NC], double (&wv)[NC], double& rho, int& nref STAMP_ARGS) const {
         double d[NC], t[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
@@ -329,8 +360,10 @@ struct Wave {
             }
         }
         wave_lds_sync();
+        STAMP(1)
         double Ax, Adt;
         gram_fused(Ax, Adt);
+        STAMP(2)
         rho = b - Ax;                       // primal_normal.cl:30-48
         const double rhs = Adt - rho;       // -(b - Ax - A d t), ldl.cl:198-219
         wave_lds_sync();
@@ -349,16 +382,21 @@ struct Wave {
             }
             const double beta2 = wave_max(fabs(diag));  // beta^2 = max |M_ii|, ldl.cl:280-294
             wave_lds_sync();
+            STAMP(3)
             factor(W, beta2, o.pivot_floor, rdiag);
+            STAMP(4)
         }
         double dy = fwd_back(rhs, rdiag);
+        STAMP(5)
         At_times(dy, wv);
+        STAMP(6)
 #pragma unroll
         for (int q = 0; q < NC; q++) dx[q] = (t[q] - wv[q]) * d[q];   // primal_normal.cl:142
         nref = 0;
         for (;;) {
             const double e = rho - A_times(dx);
             const double maxe = wave_max(fabs(e));
+            STAMP(7)
             if (!(maxe > etol) || nref >= o.max_refine) break;
             const double eta = fwd_back(e, rdiag);
             double w2[NC];
@@ -407,6 +445,7 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
     const int lane = w.lane, ri = w.ri;
     const bool rowok = ri < m;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+    STAMP_DECL
 
     for (long lp = (long)blockIdx.x * wpb + wave; lp < B; lp += (long)gridDim.x * wpb) {
         double x[NC], z[NC], c[NC], v[NC];
@@ -434,6 +473,7 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
         double normr0 = 1e300, norms0 = 1e300;
         int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
         double po = 0.0, du = 0.0;
+        STAMP(9)
 
         for (it = 0; it < o.max_iter; it++) {
             // dual infeasibility, complementarity, objectives (primal_normal.cl:76-94, 245-248)
@@ -453,7 +493,8 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
             // Newton step (also yields rho = b - Ax for the stop test of THIS point)
             double dx[NC], wv[NC], rho;
             int nref;
-            const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref);
+            STAMP(0)
+            const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref STAMP_PASS);
             const double normr = sqrt(wave_sum((lane < MP) ? rho * rho : 0.0));
 
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
@@ -481,6 +522,7 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
             }
             normr0 = normr;
             norms0 = norms;
+            STAMP(8)
         }
 
 #pragma unroll
@@ -498,7 +540,9 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
             status[lp] = stat;
             if (iters) iters[lp] = it;
         }
+        STAMP(9)
     }
+    STAMP_FLUSH(o, blockIdx.x * wpb + wave)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,7 +590,10 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
         const double etol = o.refine_tol * (1.0 + sqrt(wave_sum((lane < MP) ? b * b : 0.0)));
         double rho;
         int nref;
-        const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref);
+#ifdef PYCLLP_PROFILE
+        unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0};
+#endif
+        const double dy = w.newton(x, z, c, v, b, mu, etol, o, dx, wv, rho, nref STAMP_PASS);
         if (lane < MP && ri < m) dyg[lp * m + ri] = dy;
         if (nrefg && lane == 0) nrefg[lp] = nref;
     }
@@ -655,6 +702,11 @@ static const Variant kVariants[] = {
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
+static unsigned long long* g_prof = nullptr;  // diagnostic build only
+#ifdef PYCLLP_PROFILE
+extern "C" void pycllp_hip_debug_set_prof(void* p) { g_prof = (unsigned long long*)p; }
+#endif
+
 static DevOpts to_dev(const pycllp_hip_opts* opts) {
     pycllp_hip_opts d;
     pycllp_hip_default_opts(&d);
@@ -662,6 +714,7 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
     DevOpts o;
     o.eps = d.eps; o.delta = d.delta; o.r = d.r; o.pivot_floor = d.pivot_floor; o.refine_tol = d.refine_tol;
     o.max_iter = d.max_iter; o.max_refine = d.max_refine; o.flags = d.flags;
+    o.prof = g_prof;
     return o;
 }
 
