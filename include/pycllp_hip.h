@@ -50,6 +50,8 @@ extern "C" {
 /* flags */
 #define PYCLLP_FLAG_WARM_START 1 /* x, z, y are in/out: start from the caller's point instead of
                                     x=z=y=1 (intent of pycllp/cl/primal_normal.cl:213-219)  */
+#define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead
+                                     of the default one (one LP per 16/32-lane group)          */
 
 typedef struct pycllp_hip_opts {
     double eps;         /* relative stopping tolerance on |rho|,|sigma|,gamma; default 1e-10.

@@ -599,6 +599,8 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
     }
 }
 
+#include "ipm_group.inc"
+
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
 // ------------------------------------------------------------------------------------------------
@@ -619,6 +621,7 @@ static int set_err(int code, const char* what) {
 struct pycllp_hip_dense {
     int m, n, mp, np, variant;
     double* pack;
+    double* a_rm;   // row-major copy of A [m,n] for the group kernel
     int grid, block, lds;
     int num_cu;
     int max_lds;
@@ -673,6 +676,27 @@ static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, con
 }
 
 template <int MP, int NP>
+static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
+                                     double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
+                                     hipStream_t st) {
+    using G = GeoG<MP, NP>;
+    int wpb = 7;
+    while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
+    const long per_block = (long)wpb * G::G;
+    long blocks = (B + per_block - 1) / per_block;
+    const long resident = (long)h->num_cu * ((size_t)h->max_lds / G::lds_bytes(wpb) >= 2 ? 2 : 1);
+    if (blocks > resident) blocks = resident;
+    if (blocks < 1) blocks = 1;
+    h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
+    hipError_t e = hipFuncSetAttribute((const void*)ipm_group_kernel<MP, NP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ipm_group_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+                       h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, o);
+    return hipGetLastError();
+}
+
+template <int MP, int NP>
 static hipError_t launch_newton(pycllp_hip_dense* h, long B, const double* x, const double* z, const double* y,
                                 const double* b, const double* c, double mu, double* dy, int* nref, DevOpts o,
                                 hipStream_t st) {
@@ -688,12 +712,13 @@ static hipError_t launch_newton(pycllp_hip_dense* h, long B, const double* x, co
 struct Variant {
     int mp, np, apack;
     pack_launch_fn pack;
-    solve_launch_fn solve;
+    solve_launch_fn solve;        // wave-per-LP kernel (first generation)
+    solve_launch_fn solve_group;  // group-per-LP kernel (default)
     newton_launch_fn newton;
 };
 
 #define VARIANT(MP, NP) \
-    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_newton<MP, NP> }
+    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP>, launch_newton<MP, NP> }
 
 // ordered by cost: the first variant that covers (m, n) is used
 static const Variant kVariants[] = {
@@ -763,10 +788,13 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
     if (h->max_lds <= 0) h->max_lds = 64 * 1024;
     e = hipMalloc((void**)&h->pack, sizeof(double) * kVariants[vi].apack);
     if (e != hipSuccess) { free(h); return set_err((int)e, "hipMalloc(pack)"); }
+    e = hipMalloc((void**)&h->a_rm, sizeof(double) * (size_t)m * n);
+    if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "hipMalloc(A)"); }
     hipStream_t st = (hipStream_t)stream;
-    e = kVariants[vi].pack(h, A_dev, st);
+    e = hipMemcpyAsync(h->a_rm, A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = kVariants[vi].pack(h, A_dev, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "pack_A_kernel"); }
+    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); free(h); return set_err((int)e, "pack_A_kernel"); }
     *handle = h;
     return 0;
 }
@@ -781,9 +809,10 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
-    hipError_t e = kVariants[h->variant].solve(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev,
-                                               status_dev, iters_dev, o, (hipStream_t)stream);
-    if (e != hipSuccess) return set_err((int)e, "ipm_solve_kernel launch");
+    const Variant& v = kVariants[h->variant];
+    hipError_t e = ((o.flags & PYCLLP_FLAG_WAVE_KERNEL) ? v.solve : v.solve_group)(
+        h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o, (hipStream_t)stream);
+    if (e != hipSuccess) return set_err((int)e, "solve kernel launch");
     return 0;
 }
 
@@ -815,6 +844,7 @@ int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* bloc
 void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (!h) return;
     if (h->pack) (void)hipFree(h->pack);
+    if (h->a_rm) (void)hipFree(h->a_rm);
     free(h);
 }
 
