@@ -622,6 +622,7 @@ struct pycllp_hip_dense {
     int m, n, mp, np, variant;
     double* pack;
     double* a_rm;   // row-major copy of A [m,n] for the group kernel
+    int* queue;     // device work-queue head of the group kernel (zeroed before every launch)
     int grid, block, lds;
     int num_cu;
     int max_lds;
@@ -691,8 +692,10 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     hipError_t e = hipFuncSetAttribute((const void*)ipm_group_kernel<MP, NP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
     if (e != hipSuccess) return e;
+    e = hipMemsetAsync(h->queue, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ipm_group_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
-                       h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, o);
+                       h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, h->queue, o);
     return hipGetLastError();
 }
 
@@ -790,11 +793,13 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
     if (e != hipSuccess) { free(h); return set_err((int)e, "hipMalloc(pack)"); }
     e = hipMalloc((void**)&h->a_rm, sizeof(double) * (size_t)m * n);
     if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "hipMalloc(A)"); }
+    e = hipMalloc((void**)&h->queue, sizeof(int));
+    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); free(h); return set_err((int)e, "hipMalloc(queue)"); }
     hipStream_t st = (hipStream_t)stream;
     e = hipMemcpyAsync(h->a_rm, A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = kVariants[vi].pack(h, A_dev, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); free(h); return set_err((int)e, "pack_A_kernel"); }
+    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); (void)hipFree(h->queue); free(h); return set_err((int)e, "pack_A_kernel"); }
     *handle = h;
     return 0;
 }
@@ -845,6 +850,7 @@ void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (!h) return;
     if (h->pack) (void)hipFree(h->pack);
     if (h->a_rm) (void)hipFree(h->a_rm);
+    if (h->queue) (void)hipFree(h->queue);
     free(h);
 }
 

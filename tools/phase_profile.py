@@ -12,7 +12,8 @@ from pycllp_amd.solvers.hip import HipDensePrimalNormalSolver
 
 NPHASE = 10
 names = ["0 elementwise+reductions", "1 d,t,kbuf", "2 gram(MFMA)+Ax", "3 slab->rows,beta", "4 factor LDL", "5 fwd/back",
-         "6 A'dy", "7 A dx + maxe (refine check)", "8 stop tests + step", "9 load/store LP"]
+         "6 A'dy", "7 A dx + maxe (refine check)", "8 stop tests + step (+store)", "9 load LP"]
+LPW = 2  # LPs per wave in the group kernel at m<=32 (4 at m<=16)
 m, n, B = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 64, 65536)))
 A, b, c = problems.random_dense_arrays(m, n, B)
 Ae, be, ce = problems.equality_arrays(A, b, c)
@@ -33,6 +34,7 @@ p = prof.cpu().numpy()[:nw * NPHASE].reshape(nw, NPHASE).astype(np.float64)
 iters = buf["iters"].cpu().numpy()
 tot = p.sum(1)
 print("kernel %.2f ms (stamped build), %d waves, LP-iterations per wave %.1f" % (e0.elapsed_time(e1), nw, (iters.sum() + B) / nw))
+print("(cycles below are per LP-iteration, i.e. wave cycles divided by the LP-iterations the wave served)")
 print("cycles per wave: mean %.3g  min %.3g  max %.3g" % (tot.mean(), tot.min(), tot.max()))
 per_it = p.sum(0) / (iters.sum() + B)
 for i in range(NPHASE):

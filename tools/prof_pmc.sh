@@ -18,12 +18,14 @@ for grp in \
 done
 python3 - <<PY
 import csv,glob,collections
-agg=collections.defaultdict(list)
+vals=collections.defaultdict(list)
 for f in glob.glob("$OUT/pass*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if 'ipm_solve_kernel' in row['Kernel_Name'] and int(row['Grid_Size'])>=256*512:
-            agg[row['Counter_Name']].append(float(row['Counter_Value']))
+        if 'ipm_' in row['Kernel_Name'] and 'kernel' in row['Kernel_Name'] and 'pack' not in row['Kernel_Name']:
+            vals[row['Counter_Name']].append(float(row['Counter_Value']))
 with open("$OUT/summary.txt","w") as fo:
-    for k,v in sorted(agg.items()):
-        line="%-28s n=%d mean=%.6g"%(k,len(v),sum(v)/len(v)); print(line); fo.write(line+"\n")
+    fo.write("# per-launch means over the FULL-SIZE launches only (values > half of the maximum seen)\n")
+    for k,v in sorted(vals.items()):
+        mx=max(v); sel=[x for x in v if x>0.5*mx] if mx>0 else v
+        line="%-28s n=%d mean=%.6g"%(k,len(sel),sum(sel)/len(sel)); print(line); fo.write(line+"\n")
 PY
