@@ -28,6 +28,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "../../include/pycllp_hip.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
