@@ -50,6 +50,8 @@ extern "C" {
 /* flags */
 #define PYCLLP_FLAG_WARM_START 1 /* x, z, y are in/out: start from the caller's point instead of
                                     x=z=y=1 (intent of pycllp/cl/primal_normal.cl:213-219)  */
+#define PYCLLP_FLAG_FORCE_GUARD_PATH 4 /* diagnostic: always run the guarded (cold) LDL' path of the group
+                                          kernel; results must not change when the guard is inactive */
 #define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead
                                      of the default one (one LP per 16/32-lane group)          */
 

@@ -282,6 +282,20 @@ def test_warm_start_from_previous_solution():
     assert (buf["iters"].cpu().numpy() + cold_it).mean() < full["iters"].mean() + 3
 
 
+@pytest.mark.parametrize("flags,what", [(2, "first-generation wave-per-LP kernel"), (4, "guarded (cold) LDL' path of the group kernel")])
+@pytest.mark.parametrize("m,n", [(16, 32), (32, 64), (7, 20)])
+def test_alternative_kernel_paths_agree_with_oracle(flags, what, m, n):
+    """PYCLLP_FLAG_WAVE_KERNEL and PYCLLP_FLAG_FORCE_GUARD_PATH select code that the default launch (almost) never
+    runs; both must give the oracle's answers too."""
+    A, b, c = problems.random_dense_arrays(m, n, 1024, seed=9)
+    elp, s = solve_arrays(A, b, c, flags=flags)
+    r = oracle_on(elp)
+    np.testing.assert_array_equal(s.status, r["status"])
+    assert (s.status == 0).all()
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and (s.iters == r["iters"]).mean() > 0.99
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+
+
 def test_keep_on_device_returns_cuda_tensors():
     A, b, c = problems.random_dense_arrays(16, 32, 128, seed=6)
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
