@@ -20,6 +20,8 @@
  *   pycllp_hip_dense_newton <- kernel solve_primal_normal launched stand-alone by the reference's
  *                              tests/test_ldl.py:219-273            pycllp/cl/ldl.cl:602-653
  *   pycllp_hip_dense_free   <- release of ClDensePrimalNormalSolver.buffers  pycllp/solvers/cl.py:26
+ *   pycllp_hip_ldl          <- test kernels ldl / modified_ldl                pycllp/cl/ldl.cl:28-55, 57-107
+ *                              (host: pycllp/ldl.py:58-128, launched by tests/test_ldl.py:139-193)
  *
  * Layouts are the problem-major ones of the LP container (pycllp/lp.py:338-347), NOT the
  * batch-interleaved transposes the OpenCL host builds (pycllp/solvers/cl.py:99,102):
@@ -105,6 +107,13 @@ int pycllp_hip_dense_launch_info(const pycllp_hip_dense *handle, int *grid, int 
                                  int *m_pad, int *n_pad);
 
 void pycllp_hip_dense_free(pycllp_hip_dense *handle);
+
+/* Stand-alone batched LDL' (modified != 0: Nocedal-Wright modified LDL' with the given beta and delta) of B
+ * explicit symmetric matrices A_dev [B, n, n] (row-major, only the lower triangle is read), n <= 128.
+ * L_dev [B, n(n+1)/2]: packed lower triangle with unit diagonal, entry (i, j) at i(i+1)/2 + j; D_dev [B, n].
+ * Replaces the reference's test kernels `ldl` / `modified_ldl` (pycllp/cl/ldl.cl:28-55, 57-107). */
+int pycllp_hip_ldl(int n, long B, const double *A_dev, double *L_dev, double *D_dev, int modified, double beta,
+                   double delta, void *stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@ pycllp/solvers/cl.py).  The product is ``csrc/libpycllp_hip.so`` (hand-written H
 C ABI declared in include/pycllp_hip.h) plus this thin Python host mirroring the reference's plugin
 interface.  There is no CPU fallback: without the HIP library or a GPU the solvers raise.
 """
-from . import lp, problems, solvers  # noqa: F401
+from . import lp, problems, solvers, ldl  # noqa: F401
 from .solvers import solver_registry, BaseSolver  # noqa: F401
 
 __version__ = "0.1.0"

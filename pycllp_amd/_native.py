@@ -15,7 +15,7 @@ EXPORTS = (
     "pycllp_hip_abi_version", "pycllp_hip_last_error", "pycllp_hip_default_opts",
     "pycllp_hip_dense_max_rows", "pycllp_hip_dense_max_cols", "pycllp_hip_dense_init",
     "pycllp_hip_dense_solve", "pycllp_hip_dense_newton", "pycllp_hip_dense_launch_info",
-    "pycllp_hip_dense_free",
+    "pycllp_hip_dense_free", "pycllp_hip_ldl",
 )
 
 STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
@@ -59,6 +59,8 @@ def lib():
     L.pycllp_hip_dense_newton.restype = ctypes.c_int
     L.pycllp_hip_dense_launch_info.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int)] * 5
     L.pycllp_hip_dense_launch_info.restype = ctypes.c_int
+    L.pycllp_hip_ldl.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
+    L.pycllp_hip_ldl.restype = ctypes.c_int
     L.pycllp_hip_dense_free.argtypes = [vp]
     L.pycllp_hip_dense_free.restype = None
     if L.pycllp_hip_abi_version() != 1:

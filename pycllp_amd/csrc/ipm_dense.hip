@@ -602,6 +602,7 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
 }
 
 #include "ipm_group.inc"
+#include "ldl_batched.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -845,6 +846,28 @@ int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* bloc
     if (lds_bytes) *lds_bytes = h->lds;
     if (m_pad) *m_pad = h->mp;
     if (n_pad) *n_pad = h->np;
+    return 0;
+}
+
+int pycllp_hip_ldl(int n, long B, const double* A_dev, double* L_dev, double* D_dev, int modified, double beta,
+                   double delta, void* stream) {
+    if (n <= 0 || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl: bad argument");
+    if (B == 0) return 0;
+    if (!A_dev || !L_dev || !D_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl: bad argument");
+    if (n > LDL_MAX_N) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_ldl: n=%d exceeds the compiled kernel (n<=%d)", n, LDL_MAX_N);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    if (modified && !(beta > 0.0)) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl: beta must be positive");
+    const int threads = (n <= 64) ? 64 : 128;
+    const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) + 8));
+    hipError_t e = hipFuncSetAttribute((const void*)ldl_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(ldl_batched_kernel)");
+    long blocks = B < 4096 ? B : 4096;
+    hipLaunchKernelGGL(ldl_batched_kernel, dim3((unsigned)blocks), dim3(threads), lds, (hipStream_t)stream, n, B, A_dev,
+                       L_dev, D_dev, modified, beta, delta);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_err((int)e, "ldl_batched_kernel launch");
     return 0;
 }
 

@@ -112,6 +112,8 @@ class HipDensePrimalNormalSolver(BaseSolver):
         if warm_start:
             opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
         o = _native.default_opts(**opts)
+        if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
+            raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
         with torch.cuda.device(self.device):
             _native.check(_native.lib().pycllp_hip_dense_solve(
                 self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),

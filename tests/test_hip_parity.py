@@ -303,3 +303,51 @@ def test_keep_on_device_returns_cuda_tensors():
     lp.init(s)
     st = lp.solve(s)
     assert st.is_cuda and s.x.is_cuda and s.x.shape == (128, 48) and int((st != 0).sum()) == 0
+
+
+# ---- stand-alone LDL' kernels (reference tests/test_ldl.py:139-193: 32 random SPD matrices of 100 x 100) ------------
+
+def _spd_batch(n, B, seed):
+    from scipy.sparse import rand as sparse_rand
+    rs = np.random.RandomState(seed)
+    out = np.empty((B, n, n))
+    for i in range(B):
+        X = sparse_rand(n, 80, density=0.1, random_state=rs).toarray()       # fixture A of tests/test_ldl.py:27-31
+        out[i] = X @ X.T + np.eye(n) * n
+    return out
+
+
+@pytest.mark.parametrize("n,B", [(100, 32), (7, 5), (64, 3), (65, 2), (128, 2), (1, 4)])
+def test_ldl_kernels_against_oracle_and_cholesky(n, B):
+    from pycllp_amd import ldl as hip_ldl
+    from oracle import port
+    AA = _spd_batch(n, B, seed=n)
+    D, L = hip_ldl.ldl(AA)
+    assert D.shape == (B, n) and L.shape == (B, n, n)
+    for i in range(B):
+        Lo, Do = port.ldl(AA[i])
+        np.testing.assert_allclose(D[i], Do, rtol=1e-6, atol=1e-7)                   # tests/test_ldl.py:178-179
+        np.testing.assert_allclose(L[i], Lo, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(L[i] * np.sqrt(D[i]), np.linalg.cholesky(AA[i]), rtol=1e-9, atol=1e-10)
+    beta = float(np.sqrt(AA.max()))                                                   # tests/test_ldl.py:182
+    D2, L2 = hip_ldl.modified_ldl(AA, delta=1e-6, beta=beta)
+    for i in range(B):
+        Lo, Do = port.ldl(AA[i], modified=True, beta=beta, delta=1e-6)
+        np.testing.assert_allclose(D2[i], Do, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(L2[i], Lo, rtol=1e-6, atol=1e-7)
+    Ds, Ls = hip_ldl.ldl(AA[0])                                                       # single-matrix form, (D, L) order
+    np.testing.assert_array_equal(Ds, D[0]); np.testing.assert_array_equal(Ls, L[0])
+
+
+def test_modified_ldl_guard_bites_on_semidefinite_matrix():
+    from pycllp_amd import ldl as hip_ldl
+    from oracle import port
+    rs = np.random.RandomState(4)
+    X = rs.rand(12, 5)
+    S = X @ X.T                       # rank 5 < 12: the guard must act (tests/test_ldl.py:79-87)
+    D, L = hip_ldl.modified_ldl(S, delta=1e-6)
+    Lo, Do = port.ldl(S, modified=True, delta=1e-6)
+    assert np.isfinite(L).all() and (D >= 1e-6).all()
+    np.testing.assert_allclose(D[:5], Do[:5], rtol=1e-6)           # beyond the rank the pivots are rounding noise
+    with pytest.raises(NotImplementedError):
+        hip_ldl.ldl(np.eye(129))
