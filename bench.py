@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="development aid: run the N-rank path on ONE GPU (all ranks share cuda:0, gloo backend, "
+                         "results gathered through host memory); the numbers it prints are not benchmark results")
     args = ap.parse_args()
 
     import torch
@@ -91,10 +94,16 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback)")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if args.rehearse else dev     # where collectives run
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -115,7 +124,7 @@ def main():
     def step():
         buf = solver.solve_device(bd, cd)
         if world > 1:
-            return buf, {k: gather_batch(buf[k], sizes, dst=0) for k in fields}
+            return buf, {k: gather_batch(buf[k].to(cdev), sizes, dst=0) for k in fields}
         return buf, None
 
     for _ in range(args.warmup):
@@ -135,11 +144,11 @@ def main():
         buf = solver.solve_device(bd, cd)          # the dominant kernel, on torch's current stream
         ev[k][1].record()
         if world > 1:
-            gathered = {f: gather_batch(buf[f], sizes, dst=0) for f in fields}
+            gathered = {f: gather_batch(buf[f].to(cdev), sizes, dst=0) for f in fields}
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -150,7 +159,7 @@ def main():
     ok_local = int((status == 0).sum())
     gap = float(np.max(np.abs(pobj - dobj) / np.maximum(1.0, np.abs(pobj))))
     if world > 1:
-        agg = torch.tensor([ok_local, float(iters.sum())], dtype=torch.float64, device=dev)
+        agg = torch.tensor([ok_local, float(iters.sum())], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         ok_total, iters_mean = int(agg[0].item()), float(agg[1].item()) / (B * world)
         if rank == 0:
@@ -186,13 +195,14 @@ def main():
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL on one shared GPU: not a result)",
             "config": {"workload": "%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
                                    "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
                                    % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else ""),
                        "lps_per_gpu": B, "lps_total": B * world, "m": M, "n": N_STD, "N_equality": Nn,
                        "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world,
-                       "kernel": "ipm_solve_kernel<%d,%d> grid %d x block %d, %d B LDS"
+                       "kernel": "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
                                  % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},
             "solved_optimal": ok_total, "mean_ipm_iterations": iters_mean, "max_rel_duality_gap_rank0": gap,
             "parity": parity,
