@@ -115,6 +115,22 @@ void pycllp_hip_dense_free(pycllp_hip_dense *handle);
 int pycllp_hip_ldl(int n, long B, const double *A_dev, double *L_dev, double *D_dev, int modified, double beta,
                    double delta, void *stream);
 
+/* ---- sparse shared-A path (BASELINE config 5): one LP per workgroup, A in CSR, dense packed factor in LDS ----
+ * Replaces ClSparsePrimalNormalSolver (pycllp/solvers/cl.py:127-278) and the sparse_* kernels
+ * (pycllp/cl/primal_normal.cl:287-375, pycllp/cl/ldl.cl:140-196,221-257,381-502,540-574,656-712).
+ * init takes the CSR arrays the reference uploads (cl.py:175-178: Adata f64[nnz], Aindptr i32[m+1], Aindices i32[nnz],
+ * device pointers); A' and the structure of A diag(x/z) A' are derived inside (cl.py:180-196 does this on the host).
+ * Limits: m <= 128, n <= 512 (equality form).  solve has the semantics and layouts of pycllp_hip_dense_solve. */
+typedef struct pycllp_hip_sparse pycllp_hip_sparse;
+int pycllp_hip_sparse_max_rows(void);
+int pycllp_hip_sparse_max_cols(void);
+int pycllp_hip_sparse_init(int m, int n, int nnz, const double *Adata_dev, const int *Aindptr_dev,
+                           const int *Aindices_dev, void *stream, pycllp_hip_sparse **handle);
+int pycllp_hip_sparse_solve(pycllp_hip_sparse *handle, long B, const double *b_dev, const double *c_dev,
+                            double *x_dev, double *y_dev, double *z_dev, double *pobj_dev, double *dobj_dev,
+                            int *status_dev, int *iters_dev, const pycllp_hip_opts *opts, void *stream);
+void pycllp_hip_sparse_free(pycllp_hip_sparse *handle);
+
 #ifdef __cplusplus
 }
 #endif

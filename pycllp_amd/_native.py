@@ -16,6 +16,8 @@ EXPORTS = (
     "pycllp_hip_dense_max_rows", "pycllp_hip_dense_max_cols", "pycllp_hip_dense_init",
     "pycllp_hip_dense_solve", "pycllp_hip_dense_newton", "pycllp_hip_dense_launch_info",
     "pycllp_hip_dense_free", "pycllp_hip_ldl",
+    "pycllp_hip_sparse_max_rows", "pycllp_hip_sparse_max_cols", "pycllp_hip_sparse_init", "pycllp_hip_sparse_solve",
+    "pycllp_hip_sparse_free",
 )
 
 STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
@@ -61,6 +63,14 @@ def lib():
     L.pycllp_hip_dense_launch_info.restype = ctypes.c_int
     L.pycllp_hip_ldl.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
     L.pycllp_hip_ldl.restype = ctypes.c_int
+    L.pycllp_hip_sparse_max_rows.restype = ctypes.c_int
+    L.pycllp_hip_sparse_max_cols.restype = ctypes.c_int
+    L.pycllp_hip_sparse_init.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, ip, ip, vp, ctypes.POINTER(vp)]
+    L.pycllp_hip_sparse_init.restype = ctypes.c_int
+    L.pycllp_hip_sparse_solve.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, dp, dp, ip, ip, ctypes.POINTER(Opts), vp]
+    L.pycllp_hip_sparse_solve.restype = ctypes.c_int
+    L.pycllp_hip_sparse_free.argtypes = [vp]
+    L.pycllp_hip_sparse_free.restype = None
     L.pycllp_hip_dense_free.argtypes = [vp]
     L.pycllp_hip_dense_free.restype = None
     if L.pycllp_hip_abi_version() != 1:

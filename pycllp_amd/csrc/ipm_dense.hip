@@ -28,7 +28,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/pycllp_hip.h"
 
@@ -603,6 +605,7 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
 
 #include "ipm_group.inc"
 #include "ldl_batched.inc"
+#include "ipm_block.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -749,6 +752,23 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
     return o;
 }
 
+// ---- sparse shared-A path (one LP per workgroup) ---------------------------------------------------------------
+struct pycllp_hip_sparse {
+    BlockA desc;
+    void* dev_blob;     // one allocation holding every device array of desc
+    int* queue;
+    int lds, num_cu, grid;
+};
+
+template <typename T>
+static T* blob_put(char* host, size_t& off, const std::vector<T>& v, char* dev_base) {
+    off = (off + 15) & ~(size_t)15;
+    if (!v.empty()) memcpy(host + off, v.data(), v.size() * sizeof(T));
+    T* p = (T*)(dev_base + off);
+    off += v.size() * sizeof(T);
+    return p;
+}
+
 extern "C" {
 
 int pycllp_hip_abi_version(void) { return PYCLLP_HIP_ABI_VERSION; }
@@ -870,6 +890,134 @@ int pycllp_hip_ldl(int n, long B, const double* A_dev, double* L_dev, double* D_
     if (e != hipSuccess) return set_err((int)e, "ldl_batched_kernel launch");
     return 0;
 }
+
+
+int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const int* Aindptr_dev,
+                           const int* Aindices_dev, void* stream, pycllp_hip_sparse** handle) {
+    if (!handle || !Adata_dev || !Aindptr_dev || !Aindices_dev || m <= 0 || n <= 0 || nnz <= 0)
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: bad argument");
+    if (m > BLK_MAX_M || n > BLK_MAX_N) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_init: (m=%d, n=%d) exceeds the compiled kernel (m<=%d, n<=%d)", m, n,
+                 BLK_MAX_M, BLK_MAX_N);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<double> val(nnz);
+    std::vector<int> ptr(m + 1), col(nnz);
+    HIP_TRY(hipMemcpyAsync(val.data(), Adata_dev, sizeof(double) * nnz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ptr.data(), Aindptr_dev, sizeof(int) * (m + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(col.data(), Aindices_dev, sizeof(int) * nnz, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ptr[0] != 0 || ptr[m] != nnz) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: malformed CSR row pointer");
+    for (int i = 0; i < m; i++) if (ptr[i + 1] < ptr[i]) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: malformed CSR row pointer");
+    for (int e = 0; e < nnz; e++) if (col[e] < 0 || col[e] >= n) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: column index out of range");
+    // CSC by counting sort (rows ascending inside a column)
+    std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<double> cval(nnz);
+    for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
+    for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
+    {
+        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int i = 0; i < m; i++)
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int q = fill[col[e]]++; crow[q] = i; cval[q] = val[e]; }
+    }
+    // Gram term list: entry (i,k), i >= k, gets a term a_ij a_kj for every column j holding both rows
+    struct Term { int key, colj; double w; };
+    std::vector<Term> terms;
+    for (int j = 0; j < n; j++)
+        for (int a = cptr[j]; a < cptr[j + 1]; a++)
+            for (int b2 = cptr[j]; b2 <= a; b2++) {
+                const int i = crow[a], k = crow[b2];
+                const int hi = i > k ? i : k, lo = i > k ? k : i;
+                terms.push_back({hi * (hi + 1) / 2 + lo, j, cval[a] * cval[b2]});
+                if (terms.size() > (size_t)8 << 20) {
+                    snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_init: A is too dense for the term-list Gram assembly");
+                    return PYCLLP_E_UNSUPPORTED;
+                }
+            }
+    std::stable_sort(terms.begin(), terms.end(), [](const Term& x, const Term& y) { return x.key < y.key; });
+    std::vector<int> ent_tri, ent_ptr, term_col(terms.size());
+    std::vector<double> term_w(terms.size());
+    for (size_t t = 0; t < terms.size(); t++) {
+        if (t == 0 || terms[t].key != terms[t - 1].key) { ent_tri.push_back(terms[t].key); ent_ptr.push_back((int)t); }
+        term_col[t] = terms[t].colj; term_w[t] = terms[t].w;
+    }
+    ent_ptr.push_back((int)terms.size());
+
+    pycllp_hip_sparse* h = (pycllp_hip_sparse*)calloc(1, sizeof(pycllp_hip_sparse));
+    if (!h) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_sparse_init: out of host memory");
+    int dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) { free(h); return set_err((int)e, "hipGetDeviceProperties"); }
+    h->num_cu = prop.multiProcessorCount;
+    int max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (max_lds > 160 * 1024 || max_lds <= 0) max_lds = 160 * 1024;
+    const size_t total = 64 + sizeof(double) * (val.size() + cval.size() + term_w.size()) +
+                         sizeof(int) * (ptr.size() + col.size() + cptr.size() + crow.size() + ent_tri.size() + ent_ptr.size() +
+                                        term_col.size()) + 16 * 12;
+    std::vector<char> host(total);
+    e = hipMalloc(&h->dev_blob, total);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->queue, sizeof(int));
+    if (e != hipSuccess) { if (h->dev_blob) (void)hipFree(h->dev_blob); free(h); return set_err((int)e, "hipMalloc(sparse A)"); }
+    size_t off = 0;
+    char* db = (char*)h->dev_blob;
+    BlockA& d = h->desc;
+    d.m = m; d.n = n; d.nnz = nnz;
+    d.csr_val = blob_put(host.data(), off, val, db);   d.csr_ptr = blob_put(host.data(), off, ptr, db);
+    d.csr_col = blob_put(host.data(), off, col, db);   d.csc_val = blob_put(host.data(), off, cval, db);
+    d.csc_ptr = blob_put(host.data(), off, cptr, db);  d.csc_row = blob_put(host.data(), off, crow, db);
+    d.ent_tri = blob_put(host.data(), off, ent_tri, db); d.ent_ptr = blob_put(host.data(), off, ent_ptr, db);
+    d.term_w = blob_put(host.data(), off, term_w, db);   d.term_col = blob_put(host.data(), off, term_col, db);
+    d.n_entries = (int)ent_tri.size(); d.n_terms = (int)terms.size();
+    e = hipMemcpyAsync(h->dev_blob, host.data(), off, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h); return set_err((int)e, "upload sparse A"); }
+    const size_t base = sizeof(double) * ((size_t)m * (m + 1) / 2 + 2 * (size_t)n + 9 * (size_t)m + 8);
+    const size_t with_a = base + sizeof(double) * 2 * (size_t)nnz + sizeof(int) * (2 * (size_t)nnz + m + n + 2) + 16;
+    d.a_in_lds = with_a <= (size_t)max_lds ? 1 : 0;
+    h->lds = (int)(d.a_in_lds ? with_a : base);
+    if ((size_t)h->lds > (size_t)max_lds) {
+        (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_init: problem does not fit in LDS");
+    }
+    *handle = h;
+    return 0;
+}
+
+int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, const double* c_dev, double* x_dev,
+                            double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
+                            int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
+    if (!h || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: bad argument");
+    if (B == 0) return 0;
+    if (!b_dev || !c_dev || !x_dev || !status_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: bad argument");
+    DevOpts o = to_dev(opts);
+    if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
+    HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
+    const long per_cu = (160 * 1024) / h->lds >= 2 ? 2 : 1;
+    long blocks = (long)h->num_cu * per_cu;
+    if (blocks > B) blocks = B;
+    h->grid = (int)blocks;
+    hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
+                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, h->queue, o);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
+    return 0;
+}
+
+void pycllp_hip_sparse_free(pycllp_hip_sparse* h) {
+    if (!h) return;
+    if (h->dev_blob) (void)hipFree(h->dev_blob);
+    if (h->queue) (void)hipFree(h->queue);
+    free(h);
+}
+
+int pycllp_hip_sparse_max_rows(void) { return BLK_MAX_M; }
+int pycllp_hip_sparse_max_cols(void) { return BLK_MAX_N; }
 
 void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (!h) return;

@@ -65,3 +65,26 @@ def parallel_small_problem_arrays(nproblems=32):
     bb = (0.5 + rs.rand(nproblems, len(b))) * b
     cc = (0.5 + rs.rand(nproblems, len(c))) * c
     return A, bb, cc
+
+
+def random_sparse_arrays(m, n, nproblems, density=0.025, seed=0):
+    """BASELINE config 5 generator: A = scipy.sparse.random(m, n, density) with every row forced
+    to >= 3 non-zeros (``tests/helpers.py:47``) and -- so that the LP max c'x, Ax <= b, x >= 0 with c > 0 is bounded --
+    every column to >= 1; values U[0,1); b, c ~ U[0.5,1.5).  Returns (A csr [m,n], b, c)."""
+    import scipy.sparse as sp
+    rs = np.random.RandomState(seed)
+    A = sp.random(m, n, density=density, random_state=rs, format="lil")
+    for i in range(m):
+        need = 3 - len(A.rows[i])
+        while need > 0:
+            j = int(rs.randint(n))
+            if A[i, j] == 0:
+                A[i, j] = rs.rand()
+                need -= 1
+    col_nnz = np.asarray((sp.csc_matrix(A) != 0).sum(axis=0)).ravel()
+    for j in np.where(col_nnz == 0)[0]:
+        A[int(rs.randint(m)), int(j)] = rs.rand()
+    A = sp.csr_matrix(A)
+    b = 0.5 + rs.rand(nproblems, m)
+    c = 0.5 + rs.rand(nproblems, n)
+    return A, b, c

@@ -39,4 +39,4 @@ def register_with_pycllp():
     return True
 
 
-from .hip import HipDensePrimalNormalSolver  # noqa: E402,F401
+from .hip import HipDensePrimalNormalSolver, HipSparsePrimalNormalSolver  # noqa: E402,F401

@@ -115,12 +115,15 @@ class HipDensePrimalNormalSolver(BaseSolver):
         if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
             raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
         with torch.cuda.device(self.device):
-            _native.check(_native.lib().pycllp_hip_dense_solve(
-                self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
-                self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
-                self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_dense_solve")
+            self._launch(B, b, c, buf, o)
         self._keepalive = (b, c)
         return buf
+
+    def _launch(self, B, b, c, buf, o):
+        _native.check(_native.lib().pycllp_hip_dense_solve(
+            self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
+            self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
+            self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_dense_solve")
 
     def solve(self, lp, verbose=0):
         """Solve every problem of ``lp`` (current ``lp.b``, ``lp.c``); results in attributes."""
@@ -170,3 +173,53 @@ class HipDensePrimalNormalSolver(BaseSolver):
         _native.check(_native.lib().pycllp_hip_dense_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
                       "pycllp_hip_dense_launch_info")
         return dict(zip(("grid", "block", "lds_bytes", "m_pad", "n_pad"), [v.value for v in vals]))
+
+
+class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
+    """Drop-in for ``cl_sparse_primal_normal`` (``pycllp/solvers/cl.py:127-278``): shared SPARSE constraint matrix, one LP
+    per workgroup, m <= 128 rows and n <= 512 columns (equality form).  Same contract and result attributes as the
+    dense solver; ``init`` takes the CSR arrays of ``lp.A`` (the reference builds them from the densified A,
+    ``cl.py:175-178``), the transposed copy and the structure of A diag(x/z) A' are derived inside the library."""
+    name = 'hip_sparse_primal_normal'
+
+    def _free(self):
+        if self._handle is not None:
+            _native.lib().pycllp_hip_sparse_free(self._handle)
+            self._handle = None
+
+    def init(self, lp, verbose=0):
+        import scipy.sparse as sp
+        self.device = _require_gpu(self.device)
+        L = _native.lib()
+        m, n = int(lp.nrows), int(lp.ncols)
+        if hasattr(lp.A, "tocsr"):
+            A = sp.csr_matrix(lp.A.tocsr())
+        else:
+            A = sp.csr_matrix(np.asarray(lp.A.todense() if hasattr(lp.A, "todense") else lp.A, dtype=np.float64))
+        A = sp.csr_matrix(A, shape=(m, n))
+        A.sum_duplicates(); A.eliminate_zeros(); A.sort_indices()
+        if verbose > 0:
+            print("Initializing HipSparsePrimalNormalSolver (m=%d, n=%d, nnz=%d) on %s" % (m, n, A.nnz, self.device))
+        self._free()
+        with torch.cuda.device(self.device):
+            data = torch.as_tensor(np.ascontiguousarray(A.data, dtype=np.float64), device=self.device)
+            indptr = torch.as_tensor(np.ascontiguousarray(A.indptr, dtype=np.int32), device=self.device)
+            indices = torch.as_tensor(np.ascontiguousarray(A.indices, dtype=np.int32), device=self.device)
+            h = ctypes.c_void_p()
+            _native.check(L.pycllp_hip_sparse_init(m, n, int(A.nnz), self._ptr(data), self._ptr(indptr), self._ptr(indices),
+                                                   self._stream_ptr(), ctypes.byref(h)), "pycllp_hip_sparse_init")
+        self._handle = h
+        self.m, self.n = m, n
+        self.buffers = {}
+
+    def _launch(self, B, b, c, buf, o):
+        _native.check(_native.lib().pycllp_hip_sparse_solve(
+            self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
+            self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
+            self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_sparse_solve")
+
+    def newton_step(self, *a, **k):
+        raise NotImplementedError("the stand-alone Newton step is provided by the dense solver only")
+
+    def launch_info(self):
+        raise NotImplementedError("launch_info is provided by the dense solver only")

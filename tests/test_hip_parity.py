@@ -351,3 +351,51 @@ def test_modified_ldl_guard_bites_on_semidefinite_matrix():
     np.testing.assert_allclose(D[:5], Do[:5], rtol=1e-6)           # beyond the rank the pivots are rounding noise
     with pytest.raises(NotImplementedError):
         hip_ldl.ldl(np.eye(129))
+
+
+# ---- sparse shared-A path (reference cl_sparse_primal_normal; BASELINE config 5) -------------------------------------
+
+def _sparse_case(m, n, B, density, seed):
+    import scipy.sparse as sp
+    A, b, c = problems.random_sparse_arrays(m, n, B, density=density, seed=seed)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"]()
+    lp.init(s)
+    st = lp.solve(s)
+    return A, b, c, lp, s, st
+
+
+@pytest.mark.parametrize("m,n,B,density", [(128, 256, 96, 0.025), (128, 256, 16, 0.1), (40, 90, 64, 0.1), (12, 20, 33, 0.3),
+                                           (100, 80, 8, 1.0)])
+def test_sparse_solver_matches_oracle_and_reference_solver(m, n, B, density):
+    from oracle import port, hsd_ref
+    A, b, c, lp, s, st = _sparse_case(m, n, B, density, seed=m + n)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    np.testing.assert_array_equal(st, r["status"])
+    assert (st == 0).all()
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    np.testing.assert_allclose(s.x, r["x"], rtol=1e-5, atol=1e-6)
+    if hsd_ref.available():   # the reference's own CPU solver on the same StandardLPs (first few: it is slow at this size)
+        k = min(B, 8)
+        g = hsd_ref.solve_standard(np.asarray(A.todense()), b[:k], c[:k])
+        assert (g["status"] == 0).all()
+        assert rel_err(s.primal_obj[:k], g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj[:k], g["dobj"]).max() < OBJ_TOL
+
+
+def test_sparse_solver_edge_cases():
+    import scipy.sparse as sp
+    A, b, c = problems.random_sparse_arrays(20, 30, 5, density=0.2, seed=1)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"]()
+    lp.init(s)
+    first = lp.solve(s).copy(); x1 = s.x.copy()
+    lp.solve(s)
+    np.testing.assert_array_equal(s.x, x1)                      # deterministic: no atomics in the Gram assembly
+    big = StandardLP(SparseMatrix(matrix=sp.random(129, 10, density=0.5, random_state=0)), np.ones((1, 129)), np.ones((1, 10)), 0.0)
+    with pytest.raises(NotImplementedError):
+        big.to_equality_form().init(solver_registry["hip_sparse_primal_normal"]())
+    empty = StandardLP(SparseMatrix(matrix=A), np.zeros((0, 20)), np.zeros((0, 30)), np.zeros(0)).to_equality_form()
+    s2 = solver_registry["hip_sparse_primal_normal"]()
+    empty.init(s2)
+    assert empty.solve(s2).shape == (0,)
