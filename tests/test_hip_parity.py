@@ -399,3 +399,17 @@ def test_sparse_solver_edge_cases():
     s2 = solver_registry["hip_sparse_primal_normal"]()
     empty.init(s2)
     assert empty.solve(s2).shape == (0,)
+
+
+def test_sparse_config5_against_golden_objectives():
+    import scipy.sparse as sp
+    g = golden("config_sparse_128x256.npz")
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(int(g["m"]), int(g["n"])))
+    lp = StandardLP(SparseMatrix(matrix=A), g["b"], g["c"], 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"]()
+    lp.init(s)
+    st = lp.solve(s)
+    assert (st == 0).all() and (g["status"] == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    np.testing.assert_allclose(s.x[:16, :int(g["n"])], g["x"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s.y[:16], g["y"], rtol=1e-5, atol=1e-6)

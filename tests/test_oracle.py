@@ -137,6 +137,21 @@ def test_status_codes_infeasible_unbounded(oracle_port):
     assert r["status"][0] != 0
 
 
+def test_sparse_config_objective_parity(oracle_port):
+    """BASELINE config 5 shape (m=128, n=256, density 0.025): the oracle on the densified equality form."""
+    import scipy.sparse as sp
+    g = golden("config_sparse_128x256.npz")
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(int(g["m"]), int(g["n"])))
+    A2, b2, c2 = problems.random_sparse_arrays(int(g["m"]), int(g["n"]), g["b"].shape[0], density=float(g["density"]), seed=0)
+    assert (A != A2).nnz == 0 and np.array_equal(b2, g["b"])          # the generator reproduces the fixture
+    k = 16
+    Ae, be, ce = problems.equality_arrays(np.asarray(A.todense()), g["b"][:k], g["c"][:k])
+    r = oracle_port.dense_solve(Ae, be, ce, nthreads=8)
+    assert (r["status"] == 0).all() and (g["status"] == 0).all()
+    assert rel_err(r["pobj"], g["pobj"][:k]).max() < OBJ_TOL and rel_err(r["dobj"], g["dobj"][:k]).max() < OBJ_TOL
+    np.testing.assert_allclose(r["x"][:, :int(g["n"])], g["x"][:k], rtol=1e-5, atol=1e-6)
+
+
 def test_live_reference_solver_agrees_with_goldens():
     """Where oracle/_ref/libhsd_ref.so is present (it is built from /root/reference in this container and
     travels to the GPU box), the goldens must be reproducible from it."""

@@ -128,6 +128,17 @@ def newton_states():
     np.savez_compressed(os.path.join(OUT, "newton_states.npz"), **out)
 
 
+def baseline_sparse(m=128, n=256, density=0.025, nlp=64):
+    """BASELINE config 5 shape: shared sparse A (stored in the fixture as CSR), HSD objectives for the first LPs."""
+    A, b, c = problems.random_sparse_arrays(m, n, nlp, density=density, seed=0)
+    g = hsd(np.asarray(A.todense()), b, c)
+    np.savez_compressed(os.path.join(OUT, "config_sparse_%dx%d.npz" % (m, n)), m=m, n=n, density=density, seed=0,
+                        A_data=A.data, A_indices=A.indices, A_indptr=A.indptr, b=b, c=c,
+                        pobj=g["pobj"], dobj=g["dobj"], status=g["status"].astype(np.int8), x=g["x"][:16], y=g["y"][:16])
+    gap = np.abs(g["pobj"] - g["dobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+    print("sparse config (%d,%d,%.3f): nnz %d, status" % (m, n, density, A.nnz), np.bincount(g["status"]), "max gap", gap.max())
+
+
 if __name__ == "__main__":
     if not hsd_ref.available():
         sys.exit("oracle/_ref/libhsd_ref.so missing: run `make -C oracle` in the container that has /root/reference")
@@ -138,3 +149,4 @@ if __name__ == "__main__":
     newton_states()
     baseline_config(16, 32)
     baseline_config(32, 64)
+    baseline_sparse()
