@@ -94,7 +94,9 @@ struct DevOpts {
 #define STAMP_ARGS , unsigned long long& t_prev_, unsigned long long (&t_acc_)[NPHASE]
 #define STAMP_PASS , t_prev_, t_acc_
 #define STAMP_FLUSH(o, wid) if ((o).prof && lane == 0) { for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_]; }
+#define STAMP_FLUSH_BLOCK(o, wid) for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_];
 #else
+#define STAMP_FLUSH_BLOCK(o, wid)
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_ARGS
@@ -974,9 +976,14 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     e = hipMemcpyAsync(h->dev_blob, host.data(), off, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h); return set_err((int)e, "upload sparse A"); }
-    const size_t base = sizeof(double) * ((size_t)m * (m + 1) / 2 + 2 * (size_t)n + 9 * (size_t)m + 8);
+    // LDS plan: two workgroups per CU hide each other's LDS latency, so the CSR/CSC copy goes into LDS only when the
+    // workgroup still fits in half a CU (or when it cannot be paired anyway)
+    const size_t base = sizeof(double) * ((size_t)m * (m + 1) / 2 + 2 * (size_t)n + 8 * (size_t)m + 8);
     const size_t with_a = base + sizeof(double) * 2 * (size_t)nnz + sizeof(int) * (2 * (size_t)nnz + m + n + 2) + 16;
-    d.a_in_lds = with_a <= (size_t)max_lds ? 1 : 0;
+    const size_t half = (size_t)max_lds / 2;
+    if (with_a <= half) d.a_in_lds = 1;
+    else if (base <= half) d.a_in_lds = 0;
+    else d.a_in_lds = with_a <= (size_t)max_lds ? 1 : 0;
     h->lds = (int)(d.a_in_lds ? with_a : base);
     if ((size_t)h->lds > (size_t)max_lds) {
         (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
@@ -998,7 +1005,7 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
     HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
-    const long per_cu = (160 * 1024) / h->lds >= 2 ? 2 : 1;
+    const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     long blocks = (long)h->num_cu * per_cu;
     if (blocks > B) blocks = B;
     h->grid = (int)blocks;

@@ -383,6 +383,20 @@ def test_sparse_solver_matches_oracle_and_reference_solver(m, n, B, density):
         assert rel_err(s.primal_obj[:k], g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj[:k], g["dobj"]).max() < OBJ_TOL
 
 
+def test_sparse_solver_guarded_path_agrees():
+    """PYCLLP_FLAG_FORCE_GUARD_PATH makes the block kernel re-assemble M and run the guarded LDL' sweep."""
+    from oracle import port
+    A, b, c = problems.random_sparse_arrays(70, 120, 24, density=0.06, seed=5)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](flags=4)
+    lp.init(s)
+    st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    np.testing.assert_array_equal(st, r["status"])
+    assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+
+
 def test_sparse_solver_edge_cases():
     import scipy.sparse as sp
     A, b, c = problems.random_sparse_arrays(20, 30, 5, density=0.2, seed=1)
