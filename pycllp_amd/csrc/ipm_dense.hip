@@ -978,7 +978,8 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     if (e != hipSuccess) { (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h); return set_err((int)e, "upload sparse A"); }
     // LDS plan: two workgroups per CU hide each other's LDS latency, so the CSR/CSC copy goes into LDS only when the
     // workgroup still fits in half a CU (or when it cannot be paired anyway)
-    const size_t base = sizeof(double) * ((size_t)m * (m + 1) / 2 + 2 * (size_t)n + 8 * (size_t)m + 8);
+    const size_t mp8 = ((size_t)m + 7) & ~(size_t)7;
+    const size_t base = sizeof(double) * ((size_t)m * (m + 1) / 2 + 1 + 2 * ((size_t)n + 1) + 7 * mp8 + 8);
     const size_t with_a = base + sizeof(double) * 2 * (size_t)nnz + sizeof(int) * (2 * (size_t)nnz + m + n + 2) + 16;
     const size_t half = (size_t)max_lds / 2;
     if (with_a <= half) d.a_in_lds = 1;
