@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("dense3", "sparse5"), default="dense3",
+                    help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
+                         "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
     ap.add_argument("--rehearse", action="store_true",
                     help="development aid: run the N-rank path on ONE GPU (all ranks share cuda:0, gloo backend, "
                          "results gathered through host memory); the numbers it prints are not benchmark results")
@@ -110,11 +113,28 @@ def main():
         cpu = cpu_baseline()
 
     B = args.batch
-    A, b, c = problems.random_dense_arrays(M, N_STD, B, seed=0, shard=rank)
-    Ae, be, ce = problems.equality_arrays(A, b, c)
-    Nn = Ae.shape[1]
-    lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
-    solver = solver_registry["hip_dense_primal_normal"](device=dev)
+    sparse = args.workload == "sparse5"
+    if sparse:
+        if args.batch == B_PER_GPU:
+            B = 16384
+        m_, n_ = 128, 256
+        A, b, c = problems.random_sparse_arrays(m_, n_, B, density=0.025, seed=0)
+        if rank:
+            rs = np.random.RandomState(1000003 * rank)
+            b = 0.5 + rs.rand(B, m_); c = 0.5 + rs.rand(B, n_)
+        be, ce = b, np.hstack([c, np.zeros((B, m_))])
+        Nn = n_ + m_
+        from pycllp_amd.lp import StandardLP
+        lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
+        solver = solver_registry["hip_sparse_primal_normal"](device=dev)
+        cpu = None
+    else:
+        m_, n_ = M, N_STD
+        A, b, c = problems.random_dense_arrays(M, N_STD, B, seed=0, shard=rank)
+        Ae, be, ce = problems.equality_arrays(A, b, c)
+        Nn = Ae.shape[1]
+        lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
+        solver = solver_registry["hip_dense_primal_normal"](device=dev)
     lp.init(solver)
     bd = torch.as_tensor(be, device=dev)
     cd = torch.as_tensor(ce, device=dev)
@@ -171,7 +191,17 @@ def main():
         # parity on the committed golden LPs (outside the timed region)
         parity = None
         gpath = os.path.join(ROOT, "tests", "golden", "config_32x64.npz")
-        if os.path.exists(gpath):
+        if sparse:
+            import scipy.sparse as sp
+            g = np.load(os.path.join(ROOT, "tests", "golden", "config_sparse_128x256.npz"))
+            r = solver.solve_device(g["b"], np.hstack([g["c"], np.zeros((g["c"].shape[0], m_))]))
+            torch.cuda.synchronize(dev)
+            ep = np.abs(r["pobj"].cpu().numpy() - g["pobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+            ed = np.abs(r["dobj"].cpu().numpy() - g["dobj"]) / np.maximum(1.0, np.abs(g["dobj"]))
+            parity = {"golden_lps": int(g["pobj"].shape[0]), "max_rel_err_primal_obj": float(ep.max()),
+                      "max_rel_err_dual_obj": float(ed.max()), "tolerance": 1e-8,
+                      "source": "reference ipo.py (hsd.c) via tests/golden/config_sparse_128x256.npz"}
+        elif os.path.exists(gpath):
             g = np.load(gpath)
             A2, b2, c2 = problems.random_dense_arrays(M, N_STD, int(g["nobj"]), seed=0)
             _, b2e, c2e = problems.equality_arrays(A2, b2, c2)
@@ -184,25 +214,35 @@ def main():
                       "source": "reference ipo.py (hsd.c) via tests/golden/config_32x64.npz"}
         total = B * world * args.steps
         value = total / elapsed
-        f_lp = flops_per_lp(M, Nn, iters_mean)
+        if sparse:   # term-list Gram assembly and CSR/CSC products instead of the dense m(m+1)N + 8mN
+            nnz_e = int(A.nnz) + m_
+            coln = np.diff(sp.csc_matrix(lp.A.tocsr()).indptr)
+            n_terms = int((coln * (coln + 1) // 2).sum())
+            f_lp = iters_mean * (2 * n_terms + 8 * nnz_e + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
+        else:
+            f_lp = flops_per_lp(m_, Nn, iters_mean)
         tflops = f_lp * B / (kern_ms * 1e-3) / 1e12
-        gbs = bytes_per_lp(M, Nn) * B / (kern_ms * 1e-3) / 1e9
+        gbs = bytes_per_lp(m_, Nn) * B / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not sparse:
             traffic = json.load(open(tpath)).get("bytes_per_launch")
-        info = solver.launch_info()
+        info = solver.launch_info() if not sparse else None
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL on one shared GPU: not a result)",
-            "config": {"workload": "%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
-                                   "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
-                                   % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else ""),
-                       "lps_per_gpu": B, "lps_total": B * world, "m": M, "n": N_STD, "N_equality": Nn,
+            "config": {"workload": ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 "
+                                    "non-zeros) -> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)"
+                                    % (B, m_, n_, Nn)) if sparse else
+                                   ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
+                                    "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
+                                    % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
+                       "lps_per_gpu": B, "lps_total": B * world, "m": m_, "n": n_, "N_equality": Nn,
                        "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world,
-                       "kernel": "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
+                       "kernel": "ipm_block_kernel (one LP per 256-thread workgroup)" if sparse else
+                                 "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
                                  % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},
             "solved_optimal": ok_total, "mean_ipm_iterations": iters_mean, "max_rel_duality_gap_rank0": gap,
             "parity": parity,
