@@ -1,0 +1,58 @@
+"""Randomised parity sweep of the HIP solvers against the oracle (development aid, run on the GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from pycllp_amd import problems
+from pycllp_amd.lp import SparseMatrix, StandardLP, EqualityLP
+from pycllp_amd.solvers import solver_registry
+from oracle import port
+
+rs = np.random.RandomState(int(os.environ.get("FUZZ_SEED", 1)))
+rel = lambda a, r: np.abs(a - r) / np.maximum(1.0, np.abs(r))
+bad = 0
+
+def check(tag, s, st, r):
+    global bad
+    same = np.array_equal(st, r["status"])
+    okm = st == 0
+    ep = rel(s.primal_obj[okm], r["pobj"][okm]).max() if okm.any() else 0.0
+    ed = rel(s.dual_obj[okm], r["dobj"][okm]).max() if okm.any() else 0.0
+    dit = np.abs(s.iters.astype(int) - r["iters"]).max()
+    flag = "" if (same and ep < 1e-8 and ed < 1e-8 and dit <= 2) else "   <-- MISMATCH"
+    bad += bool(flag)
+    print("%-58s status %s same=%s  obj err %.1e %.1e  |d iters| %d%s" % (tag, np.bincount(st, minlength=6).tolist(), same, ep, ed, dit, flag))
+
+# dense, random shapes and scales
+for t in range(int(os.environ.get("FUZZ_N", 24))):
+    m = int(rs.randint(1, 33)); n = int(rs.randint(1, 129 - m)); B = int(rs.choice([1, 3, 17, 130, 700]))
+    A = rs.rand(m, n) * (rs.rand(m, n) < rs.choice([1.0, 0.5, 0.2]))
+    A[:, A.sum(0) == 0] = 0.5                      # keep the LP bounded
+    # b, c within a decade of 1: the reference algorithm (x=z=y=1 start, unit-floored tolerances) is not scale
+    # invariant; far-off scalings converge slowly and chaotically in BOTH implementations
+    sb, sc = 10.0 ** rs.randint(-1, 2), 10.0 ** rs.randint(-1, 2)
+    b = sb * (0.5 + rs.rand(B, m)); c = sc * (0.5 + rs.rand(B, n))
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    check("dense m=%d n=%d B=%d scale b %.0e c %.0e" % (m, n, B, sb, sc), s, st, r)
+
+# dense: rank-deficient A (duplicated rows), equality LPs with mixed-sign A
+A = rs.rand(6, 14); A = np.vstack([A, A[:3]]); b = 0.5 + rs.rand(40, 6); b = np.hstack([b, b[:, :3]]); c = 0.5 + rs.rand(40, 14)
+lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
+check("dense duplicated rows (rank deficient)", s, st, port.dense_solve(lp.A.todense(), lp.b, lp.c))
+A = rs.randn(10, 30); x0 = rs.rand(64, 30) + 0.1; b = x0 @ A.T; y0 = rs.randn(64, 10); c = y0 @ A - (rs.rand(64, 30) + 0.1)
+lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)
+s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
+check("equality LP, mixed-sign A, strictly feasible pair", s, st, port.dense_solve(A, b, c))
+
+# sparse, random shapes
+for t in range(int(os.environ.get("FUZZ_NS", 8))):
+    m = int(rs.randint(2, 129)); n = int(rs.randint(2, 513 - m)); B = int(rs.choice([1, 5, 40]))
+    dens = float(rs.choice([0.02, 0.05, 0.2]))
+    A, b, c = problems.random_sparse_arrays(m, n, B, density=max(dens, 3.0 / n), seed=int(rs.randint(1 << 30)))
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](); lp.init(s); st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    check("sparse m=%d n=%d B=%d density %.2f nnz %d" % (m, n, B, dens, A.nnz), s, st, r)
+print("mismatches:", bad)
