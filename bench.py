@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--workload", choices=("dense3", "sparse5"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
+    ap.add_argument("--sync-gather", action="store_true", help="block on the result gather after every solve (no overlap)")
     ap.add_argument("--rehearse", action="store_true",
                     help="development aid: run the N-rank path on ONE GPU (all ranks share cuda:0, gloo backend, "
                          "results gathered through host memory); the numbers it prints are not benchmark results")
@@ -141,14 +142,46 @@ def main():
     sizes = [B] * world
     fields = ("pobj", "dobj", "status", "iters", "x", "y")
 
-    def step():
-        buf = solver.solve_device(bd, cd)
-        if world > 1:
-            return buf, {k: gather_batch(buf[k].to(cdev), sizes, dst=0) for k in fields}
-        return buf, None
+    # Result gather to rank 0 (the path's one collective).  It is issued asynchronously and overlaps the NEXT step's
+    # solve: outputs are double-buffered (slot k%2), receive buffers on rank 0 too, and a slot is reused only after the
+    # gather that read it has completed.  --sync-gather falls back to a blocking gather after every solve.
+    recv = None
+    if world > 1 and rank == 0:
+        shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "x": (B, Nn), "y": (B, m_)}
+        dts = {"status": torch.int32, "iters": torch.int32}
+        recv = [{f: [torch.empty(shapes[f], dtype=dts.get(f, torch.float64), device=cdev) for _ in range(world)]
+                 for f in fields} for _ in range(2)]
+    pending = [None, None]
 
-    for _ in range(args.warmup):
-        step()
+    def wait_slot(sl):
+        if pending[sl] is not None:
+            for wk in pending[sl]:
+                wk.wait()
+            pending[sl] = None
+
+    def step(k, e0=None, e1=None):
+        sl = k % 2
+        wait_slot(sl)
+        if e0 is not None:
+            e0.record()
+        buf = solver.solve_device(bd, cd, slot=sl)     # the dominant kernel, on torch's current stream
+        if e1 is not None:
+            e1.record()
+        if world > 1:
+            works = []
+            for f in fields:
+                t = buf[f].to(cdev) if args.rehearse else buf[f]
+                works.append(dist.gather(t, recv[sl][f] if rank == 0 else None, dst=0, async_op=True))
+            if args.sync_gather:
+                for wk in works:
+                    wk.wait()
+            else:
+                pending[sl] = works
+        return buf
+
+    for k in range(args.warmup):
+        step(k)
+    wait_slot(0); wait_slot(1)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def fence():
@@ -160,17 +193,18 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        buf = solver.solve_device(bd, cd)          # the dominant kernel, on torch's current stream
-        ev[k][1].record()
-        if world > 1:
-            gathered = {f: gather_batch(buf[f].to(cdev), sizes, dst=0) for f in fields}
+        buf = step(k, ev[k][0], ev[k][1])
+    wait_slot(0); wait_slot(1)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    gathered = None
+    if world > 1 and rank == 0:
+        last = (args.steps - 1) % 2
+        gathered = {f: torch.cat(recv[last][f], dim=0) for f in fields}
 
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
     status = buf["status"].cpu().numpy()
@@ -184,6 +218,9 @@ def main():
         ok_total, iters_mean = int(agg[0].item()), float(agg[1].item()) / (B * world)
         if rank == 0:
             assert gathered["x"].shape == (B * world, Nn) and gathered["status"].shape == (B * world,)
+            # rank 0's own shard must have come through the collective unchanged
+            assert torch.equal(gathered["pobj"][:B].to(dev), buf["pobj"]) and torch.equal(gathered["x"][:B].to(dev), buf["x"])
+            assert int((gathered["status"] == 0).sum()) == ok_total
     else:
         ok_total, iters_mean = ok_local, float(iters.mean())
 

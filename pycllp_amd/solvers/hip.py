@@ -86,18 +86,23 @@ class HipDensePrimalNormalSolver(BaseSolver):
         self.m, self.n = m, n
         self.buffers = {}
 
-    def _buffers(self, B):
-        if self.buffers.get("B") != B:
+    def _buffers(self, B, slot=0):
+        """Output tensors of one solve.  ``slot`` selects one of several independent sets so that a caller can keep
+        the results of solve k alive (e.g. while they are being gathered) during solve k+1."""
+        key = "set%d" % slot
+        cur = self.buffers.get(key)
+        if cur is None or cur["B"] != B:
             dev, f64, i32 = self.device, torch.float64, torch.int32
-            self.buffers = dict(
+            cur = dict(
                 B=B,
                 x=torch.empty((B, self.n), dtype=f64, device=dev), z=torch.empty((B, self.n), dtype=f64, device=dev),
                 y=torch.empty((B, self.m), dtype=f64, device=dev),
                 pobj=torch.empty(B, dtype=f64, device=dev), dobj=torch.empty(B, dtype=f64, device=dev),
                 status=torch.empty(B, dtype=i32, device=dev), iters=torch.empty(B, dtype=i32, device=dev))
-        return self.buffers
+            self.buffers[key] = cur
+        return cur
 
-    def solve_device(self, b, c, warm_start=False, **options):
+    def solve_device(self, b, c, warm_start=False, slot=0, **options):
         """Device-resident entry: b [B,m], c [B,n] (torch CUDA or numpy) -> dict of CUDA tensors.
         Asynchronous on the solver's stream."""
         if self._handle is None:
@@ -107,7 +112,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
             raise ValueError("b must be [B,%d] and c [B,%d] with equal B; got %r and %r"
                              % (self.m, self.n, tuple(b.shape), tuple(c.shape)))
         B = int(b.shape[0])
-        buf = self._buffers(B)
+        buf = self._buffers(B, slot)
         opts = dict(self.options); opts.update(options)
         if warm_start:
             opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
