@@ -52,6 +52,9 @@ extern "C" {
 /* flags */
 #define PYCLLP_FLAG_WARM_START 1 /* x, z, y are in/out: start from the caller's point instead of
                                     x=z=y=1 (intent of pycllp/cl/primal_normal.cl:213-219)  */
+#define PYCLLP_FLAG_AUTOSCALE 8 /* solve every LP with b/max|b| and c/max|c| and scale the results back: makes the
+                                   unit-floored tolerances and the x=z=y=1 start scale invariant (not in the reference;
+                                   not available with PYCLLP_FLAG_WAVE_KERNEL)                                       */
 #define PYCLLP_FLAG_FORCE_GUARD_PATH 4 /* diagnostic: always run the guarded (cold) LDL' path of the group
                                           kernel; results must not change when the guard is inactive */
 #define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead

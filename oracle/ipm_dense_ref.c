@@ -47,7 +47,8 @@ typedef struct oracle_opts {
     double refine_tol;  /* refinement tolerance, relative to 1+|b| (ldl.cl:645 is 1e-8 absolute) */
     int max_iter;       /* MAX_ITER                    (primal_normal.cl:9)        */
     int max_refine;     /* refinement passes           (ldl.cl:645)                */
-    int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219) */
+    int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219);
+                           bit3 (8): autoscale -- solve with b/max|b|, c/max|c| and scale the results back */
 } oracle_opts;
 
 void oracle_default_opts(oracle_opts *o) {
@@ -243,9 +244,39 @@ int oracle_solve_primal_normal(int m, int N, const double *A, const double *x, c
  * One LP: max c'x s.t. Ax = b, x >= 0 (equality form, lp.py:306-330), the loop of
  * primal_normal.cl:201-284 with the step of primal_normal.cl:122-156.
  */
+static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                       double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                       work *wk);
+
+/* wrapper implementing the optional scaling (not in the reference): b/max|b|, c/max|c| */
 static int ipm_one(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
                    double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
                    work *wk) {
+    if (!(o->flags & 8)) return ipm_one_raw(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+    double sb = 0.0, sc = 0.0;
+    for (int i = 0; i < m; i++) sb = fmax(sb, fabs(b[i]));
+    for (int j = 0; j < N; j++) sc = fmax(sc, fabs(c[j]));
+    if (!(sb > 0.0)) sb = 1.0;
+    if (!(sc > 0.0)) sc = 1.0;
+    double *bs = (double *)malloc(sizeof(double) * m), *cs = (double *)malloc(sizeof(double) * N);
+    for (int i = 0; i < m; i++) bs[i] = b[i] / sb;
+    for (int j = 0; j < N; j++) cs[j] = c[j] / sc;
+    if (o->flags & 1) {
+        for (int i = 0; i < m; i++) y[i] = y[i] / sc;
+        for (int j = 0; j < N; j++) { x[j] = x[j] / sb; z[j] = z[j] / sc; }
+    }
+    int st = ipm_one_raw(m, N, A, bs, cs, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+    for (int i = 0; i < m; i++) y[i] = y[i] * sc;
+    for (int j = 0; j < N; j++) { x[j] = x[j] * sb; z[j] = z[j] * sc; }
+    *pobj = *pobj * (sb * sc);
+    *dobj = *dobj * (sb * sc);
+    free(bs); free(cs);
+    return st;
+}
+
+static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                       double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                       work *wk) {
     int stat = 5;
     if (!(o->flags & 1)) { /* initialize_xzyw, primal_normal.cl:14-28 */
         for (int j = 0; j < N; j++) { x[j] = 1.0; z[j] = 1.0; }

@@ -839,6 +839,8 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
+    if ((o.flags & PYCLLP_FLAG_AUTOSCALE) && (o.flags & PYCLLP_FLAG_WAVE_KERNEL))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_AUTOSCALE is not available with PYCLLP_FLAG_WAVE_KERNEL");
     const Variant& v = kVariants[h->variant];
     hipError_t e = ((o.flags & PYCLLP_FLAG_WAVE_KERNEL) ? v.solve : v.solve_group)(
         h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o, (hipStream_t)stream);

@@ -427,3 +427,42 @@ def test_sparse_config5_against_golden_objectives():
     assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
     np.testing.assert_allclose(s.x[:16, :int(g["n"])], g["x"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(s.y[:16], g["y"], rtol=1e-5, atol=1e-6)
+
+
+# ---- autoscale option (not in the reference) -------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_autoscale_on_badly_scaled_lps(kind):
+    """b ~ 1e-3, c ~ 1e+2: the reference algorithm needs up to 170 iterations and is only 1e-7 accurate; with
+    autoscale=True the solve behaves as on a well-scaled LP.  Parity against the oracle running the same option."""
+    from oracle import port
+    rs = np.random.RandomState(5)
+    if kind == "dense":
+        m, n, B = 11, 33, 130
+        A = rs.rand(m, n)
+        name = "hip_dense_primal_normal"
+    else:
+        m, n, B = 60, 140, 24
+        A, _, _ = problems.random_sparse_arrays(m, n, 1, density=0.08, seed=3)
+        name = "hip_sparse_primal_normal"
+    b = 1e-3 * (0.5 + rs.rand(B, m)); c = 1e2 * (0.5 + rs.rand(B, n))
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry[name](autoscale=True)
+    lp.init(s)
+    st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8, flags=8)
+    np.testing.assert_array_equal(st, r["status"])
+    assert (st == 0).all() and s.iters.max() < 60 and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    pure = lambda a, ref: (np.abs(a - ref) / np.abs(ref)).max()
+    assert pure(s.primal_obj, r["pobj"]) < 1e-9 and pure(s.dual_obj, r["dobj"]) < 1e-9
+    assert pure(s.primal_obj, s.dual_obj) < 1e-9                                   # scale-free optimality
+    Ae = lp.A.todense()
+    assert np.abs(s.x @ Ae.T - lp.b).max() < 1e-9 * np.abs(lp.b).max() * 10
+    np.testing.assert_allclose(s.x, r["x"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(s.y, r["y"], rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        if kind == "dense":
+            s2 = solver_registry[name](autoscale=True, flags=2)   # not available with the wave kernel
+            lp.init(s2); lp.solve(s2)
+        else:
+            raise ValueError("n/a")
