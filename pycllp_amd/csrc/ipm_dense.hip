@@ -86,11 +86,16 @@ struct DevOpts {
 // In-kernel phase stamps (diagnostic build only; the shipped library has no stamp executing).
 #ifdef PYCLLP_PROFILE
 #define NPHASE 10
+#ifdef PYCLLP_PROFILE_LITE   // fewer live counters: the full set costs registers and distorts a kernel at the VGPR limit
+#define PHASE_MAP(i) ((i) <= 1 ? 0 : (i) == 2 ? 2 : (i) <= 4 ? 4 : (i) == 5 ? 5 : (i) <= 7 ? 6 : 8)
+#else
+#define PHASE_MAP(i) (i)
+#endif
 #define STAMP_DECL unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0}; \
     { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(i) { unsigned long long t_now_; __builtin_amdgcn_sched_barrier(0); \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    t_acc_[i] += t_now_ - t_prev_; t_prev_ = t_now_; }
+    t_acc_[PHASE_MAP(i)] += t_now_ - t_prev_; t_prev_ = t_now_; }
 #define STAMP_ARGS , unsigned long long& t_prev_, unsigned long long (&t_acc_)[NPHASE]
 #define STAMP_PASS , t_prev_, t_acc_
 #define STAMP_FLUSH(o, wid) if ((o).prof && lane == 0) { for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_]; }
