@@ -55,6 +55,8 @@ extern "C" {
 #define PYCLLP_FLAG_AUTOSCALE 8 /* solve every LP with b/max|b| and c/max|c| and scale the results back: makes the
                                    unit-floored tolerances and the x=z=y=1 start scale invariant (not in the reference;
                                    not available with PYCLLP_FLAG_WAVE_KERNEL)                                       */
+#define PYCLLP_FLAG_NO_SLACK_PATH 16 /* do not use the slack-aware kernel even when the last m columns of A are the
+                                        identity (diagnostic: results must agree to rounding)                    */
 #define PYCLLP_FLAG_FORCE_GUARD_PATH 4 /* diagnostic: always run the guarded (cold) LDL' path of the group
                                           kernel; results must not change when the guard is inactive */
 #define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead

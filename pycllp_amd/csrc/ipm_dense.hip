@@ -636,6 +636,7 @@ struct pycllp_hip_dense {
     double* pack;
     double* a_rm;   // row-major copy of A [m,n] for the group kernel
     int* queue;     // device work-queue head of the group kernel (zeroed before every launch)
+    int variant_sl; // index into kSlackVariants when the last m columns of A are the identity, else -1
     int grid, block, lds;
     int num_cu;
     int max_lds;
@@ -689,11 +690,11 @@ static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, con
     return hipGetLastError();
 }
 
-template <int MP, int NP>
+template <int MP, int NP, bool SL>
 static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
                                      double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                      hipStream_t st) {
-    using G = GeoG<MP, NP>;
+    using G = GeoG<MP, NP, SL>;
     int wpb = PYCLLP_WPB;
     while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
     const long per_block = (long)wpb * G::G;
@@ -702,12 +703,13 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
-    hipError_t e = hipFuncSetAttribute((const void*)ipm_group_kernel<MP, NP>,
+    h->mp = MP; h->np = NP;
+    hipError_t e = hipFuncSetAttribute((const void*)ipm_group_kernel<MP, NP, SL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(h->queue, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_group_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+    hipLaunchKernelGGL((ipm_group_kernel<MP, NP, SL>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
                        h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, h->queue, o);
     return hipGetLastError();
 }
@@ -734,7 +736,7 @@ struct Variant {
 };
 
 #define VARIANT(MP, NP) \
-    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP>, launch_newton<MP, NP> }
+    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP, false>, launch_newton<MP, NP> }
 
 // ordered by cost: the first variant that covers (m, n) is used
 static const Variant kVariants[] = {
@@ -742,6 +744,15 @@ static const Variant kVariants[] = {
     VARIANT(32, 96), VARIANT(32, 128),
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+// slack-aware group kernels: (MP, NP) with NP - MP padded dense columns + the m identity columns
+struct SlackVariant { int mp, np; solve_launch_fn solve_group; };
+static const SlackVariant kSlackVariants[] = {
+    {16, 32, launch_solve_group<16, 32, true>}, {16, 48, launch_solve_group<16, 48, true>},
+    {16, 64, launch_solve_group<16, 64, true>}, {32, 64, launch_solve_group<32, 64, true>},
+    {32, 96, launch_solve_group<32, 96, true>}, {32, 128, launch_solve_group<32, 128, true>},
+};
+static const int kNumSlackVariants = sizeof(kSlackVariants) / sizeof(kSlackVariants[0]);
 
 static unsigned long long* g_prof = nullptr;  // diagnostic build only
 #ifdef PYCLLP_PROFILE
@@ -828,6 +839,22 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
     hipStream_t st = (hipStream_t)stream;
     e = hipMemcpyAsync(h->a_rm, A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = kVariants[vi].pack(h, A_dev, st);
+    // is A = [A_dense | I_m]?  (equality form of a StandardLP, pycllp/lp.py:551-567)
+    h->variant_sl = -1;
+    if (e == hipSuccess && n > m) {
+        std::vector<double> Ah((size_t)m * n);
+        e = hipMemcpyAsync(Ah.data(), A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) {
+            bool ident = true;
+            for (int i = 0; i < m && ident; i++)
+                for (int k = 0; k < m; k++)
+                    if (Ah[(size_t)i * n + (n - m) + k] != (i == k ? 1.0 : 0.0)) { ident = false; break; }
+            if (ident)
+                for (int i = 0; i < kNumSlackVariants; i++)
+                    if (m <= kSlackVariants[i].mp && n - m <= kSlackVariants[i].np - kSlackVariants[i].mp) { h->variant_sl = i; break; }
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); (void)hipFree(h->queue); free(h); return set_err((int)e, "pack_A_kernel"); }
     *handle = h;
@@ -847,8 +874,11 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
     if ((o.flags & PYCLLP_FLAG_AUTOSCALE) && (o.flags & PYCLLP_FLAG_WAVE_KERNEL))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_AUTOSCALE is not available with PYCLLP_FLAG_WAVE_KERNEL");
     const Variant& v = kVariants[h->variant];
-    hipError_t e = ((o.flags & PYCLLP_FLAG_WAVE_KERNEL) ? v.solve : v.solve_group)(
-        h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o, (hipStream_t)stream);
+    solve_launch_fn fn = v.solve_group;
+    if (o.flags & PYCLLP_FLAG_WAVE_KERNEL) fn = v.solve;
+    else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH)) fn = kSlackVariants[h->variant_sl].solve_group;
+    hipError_t e = fn(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o,
+                      (hipStream_t)stream);
     if (e != hipSuccess) return set_err((int)e, "solve kernel launch");
     return 0;
 }

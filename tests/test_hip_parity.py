@@ -282,7 +282,8 @@ def test_warm_start_from_previous_solution():
     assert (buf["iters"].cpu().numpy() + cold_it).mean() < full["iters"].mean() + 3
 
 
-@pytest.mark.parametrize("flags,what", [(2, "first-generation wave-per-LP kernel"), (4, "guarded (cold) LDL' path of the group kernel")])
+@pytest.mark.parametrize("flags,what", [(2, "first-generation wave-per-LP kernel"), (4, "guarded (cold) LDL' path of the group kernel"),
+                                        (16, "generic group kernel although A = [A | I]"), (16 + 4, "generic group kernel, guarded path")])
 @pytest.mark.parametrize("m,n", [(16, 32), (32, 64), (7, 20)])
 def test_alternative_kernel_paths_agree_with_oracle(flags, what, m, n):
     """PYCLLP_FLAG_WAVE_KERNEL and PYCLLP_FLAG_FORCE_GUARD_PATH select code that the default launch (almost) never
