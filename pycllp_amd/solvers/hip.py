@@ -135,26 +135,94 @@ class HipDensePrimalNormalSolver(BaseSolver):
             self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
             self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_dense_solve")
 
+    # -- host-to-host path -----------------------------------------------------------------------
+    PIPELINE_MIN_BATCH = 8192   # below this one upload / launch / download is as fast
+    PIPELINE_CHUNKS = 8
+
+    def _host_staging(self, B):
+        """Page-locked host images of b, c and of every result, allocated once per batch size (the counterpart of
+        the host arrays ``pycllp/solvers/cl.py:40-41`` keeps) plus the two copy streams of the pipeline."""
+        st = self.buffers.get("host")
+        if st is None or st["B"] != B:
+            f64, i32 = torch.float64, torch.int32
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+            st = dict(B=B, b=pin((B, self.m), f64), c=pin((B, self.n), f64),
+                      x=pin((B, self.n), f64), z=pin((B, self.n), f64), y=pin((B, self.m), f64),
+                      pobj=pin((B,), f64), dobj=pin((B,), f64), status=pin((B,), i32), iters=pin((B,), i32),
+                      db=torch.empty((B, self.m), dtype=f64, device=self.device),
+                      dc=torch.empty((B, self.n), dtype=f64, device=self.device),
+                      s_in=torch.cuda.Stream(self.device), s_out=torch.cuda.Stream(self.device))
+            st["hb"], st["hc"] = st["b"].numpy(), st["c"].numpy()
+            self.buffers["host"] = st
+        return st
+
+    def _solve_host(self, b, c):
+        """numpy in, numpy out, as a three-stage pipeline over row chunks of the batch: upload chunk k+1, solve
+        chunk k and download chunk k-1 run on three HIP streams, so the PCIe time hides behind the kernel.  The
+        returned arrays are views of the solver's page-locked buffers and are overwritten by the next solve()
+        (the reference's ``self.x`` behaves the same way, ``pycllp/solvers/cl.py:40,119``)."""
+        b = np.ascontiguousarray(b, dtype=np.float64); c = np.ascontiguousarray(c, dtype=np.float64)
+        if b.ndim != 2 or c.ndim != 2 or b.shape[1] != self.m or c.shape[1] != self.n or b.shape[0] != c.shape[0]:
+            raise ValueError("b must be [B,%d] and c [B,%d] with equal B; got %r and %r"
+                             % (self.m, self.n, tuple(b.shape), tuple(c.shape)))
+        B = int(b.shape[0])
+        st, buf = self._host_staging(B), self._buffers(B, 0)
+        o = _native.default_opts(**self.options)
+        if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
+            raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
+        nchunk = max(1, min(self.PIPELINE_CHUNKS, B // self.PIPELINE_MIN_BATCH))
+        edges = [B * k // nchunk for k in range(nchunk + 1)]
+        compute = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        outs = ("x", "y", "z", "pobj", "dobj", "status", "iters")
+        with torch.cuda.device(self.device):
+            for lo, hi in zip(edges[:-1], edges[1:]):
+                # plain memcpy on this thread: torch's CPU copy_ would wake its whole intra-op thread pool, whose
+                # spin-waiting burns a container's CPU quota and shows up as sporadic ~80 ms stalls
+                np.copyto(st["hb"][lo:hi], b[lo:hi]); np.copyto(st["hc"][lo:hi], c[lo:hi])
+                with torch.cuda.stream(st["s_in"]):
+                    st["db"][lo:hi].copy_(st["b"][lo:hi], non_blocking=True)
+                    st["dc"][lo:hi].copy_(st["c"][lo:hi], non_blocking=True)
+                    up = st["s_in"].record_event()
+                compute.wait_event(up)
+                part = {k: buf[k][lo:hi] for k in outs}
+                self._launch(hi - lo, st["db"][lo:hi], st["dc"][lo:hi], part, o)
+                done = compute.record_event()
+                with torch.cuda.stream(st["s_out"]):
+                    st["s_out"].wait_event(done)
+                    for k in outs:
+                        st[k][lo:hi].copy_(part[k], non_blocking=True)
+            st["s_out"].synchronize()
+        return {k: st[k].numpy() for k in outs}
+
     def solve(self, lp, verbose=0):
         """Solve every problem of ``lp`` (current ``lp.b``, ``lp.c``); results in attributes."""
         if int(lp.nrows) != self.m or int(lp.ncols) != self.n:
             raise ValueError("LP shape changed since init(): (%d,%d) vs (%d,%d)" % (lp.nrows, lp.ncols, self.m, self.n))
+        if self._handle is None:
+            raise RuntimeError("solve() called before init()")
         if verbose > 0:
-            print("Solving %d LPs with HipDensePrimalNormalSolver..." % lp.nproblems)
-        buf = self.solve_device(lp.b, lp.c)
-        torch.cuda.synchronize(self.device)
+            print("Solving %d LPs with %s..." % (lp.nproblems, type(self).__name__))
         f = np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)
-        if self.keep_on_device:
-            self.x, self.y, self.z = buf["x"], buf["y"], buf["z"]
-            self.status, self.iters = buf["status"], buf["iters"]
-            ft = torch.as_tensor(np.broadcast_to(f, (buf["B"],)).copy(), device=self.device)
-            self.primal_obj, self.dual_obj = buf["pobj"] + ft, buf["dobj"] + ft
-        else:
-            self.x = buf["x"].cpu().numpy(); self.y = buf["y"].cpu().numpy(); self.z = buf["z"].cpu().numpy()
-            self.status = buf["status"].cpu().numpy(); self.iters = buf["iters"].cpu().numpy()
+        on_host = not isinstance(lp.b, torch.Tensor) and not isinstance(lp.c, torch.Tensor)
+        if on_host and not self.keep_on_device:
+            res = self._solve_host(lp.b, lp.c)
+            self.x, self.y, self.z = res["x"], res["y"], res["z"]
+            self.status, self.iters = res["status"], res["iters"]
             # objective offset f is added when reporting (as pycllp/solvers/pathfollowing.py:113-114)
-            self.primal_obj = buf["pobj"].cpu().numpy() + f
-            self.dual_obj = buf["dobj"].cpu().numpy() + f
+            self.primal_obj, self.dual_obj = res["pobj"] + f, res["dobj"] + f
+        else:
+            buf = self.solve_device(lp.b, lp.c)
+            torch.cuda.synchronize(self.device)
+            if self.keep_on_device:
+                self.x, self.y, self.z = buf["x"], buf["y"], buf["z"]
+                self.status, self.iters = buf["status"], buf["iters"]
+                ft = torch.as_tensor(np.broadcast_to(f, (buf["B"],)).copy(), device=self.device)
+                self.primal_obj, self.dual_obj = buf["pobj"] + ft, buf["dobj"] + ft
+            else:
+                self.x = buf["x"].cpu().numpy(); self.y = buf["y"].cpu().numpy(); self.z = buf["z"].cpu().numpy()
+                self.status = buf["status"].cpu().numpy(); self.iters = buf["iters"].cpu().numpy()
+                self.primal_obj = buf["pobj"].cpu().numpy() + f
+                self.dual_obj = buf["dobj"].cpu().numpy() + f
         if verbose > 0:
             print("Solve complete.")
         return self.status

@@ -197,6 +197,27 @@ def test_ragged_batch_sizes(B):
     assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9
 
 
+def test_host_pipeline_equals_device_resident_solve():
+    """lp.solve() on numpy inputs runs the chunked upload/solve/download pipeline; it must give exactly what one
+    device-resident launch over the whole batch gives, and a second solve must reuse the buffers correctly."""
+    A, b, c = problems.random_dense_arrays(12, 20, 20011, seed=5)     # 2 ragged chunks
+    elp, s = solve_arrays(A, b, c)
+    assert isinstance(s.x, np.ndarray) and s.x.shape == (20011, 32)
+    host = {k: np.array(getattr(s, k)) for k in ("x", "y", "z", "primal_obj", "dual_obj", "status", "iters")}
+    buf = s.solve_device(elp.b, elp.c, slot=1)
+    torch.cuda.synchronize()
+    for k, kb in (("x", "x"), ("y", "y"), ("z", "z"), ("primal_obj", "pobj"), ("dual_obj", "dobj"),
+                  ("status", "status"), ("iters", "iters")):
+        np.testing.assert_array_equal(host[k], buf[kb].cpu().numpy(), err_msg=k)
+    b0 = elp.b
+    elp.b = b0 * 1.5
+    elp.solve(s)
+    assert not np.array_equal(s.primal_obj, host["primal_obj"])
+    elp.b = b0
+    elp.solve(s)
+    np.testing.assert_array_equal(s.x, host["x"])
+
+
 def test_empty_batch():
     A = np.random.RandomState(0).rand(4, 6)
     lp = StandardLP(SparseMatrix(matrix=A), np.zeros((0, 4)), np.zeros((0, 6)), np.zeros(0)).to_equality_form()

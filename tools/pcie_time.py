@@ -11,7 +11,23 @@ lp = EqualityLP(SparseMatrix(matrix=Ae), be, ce, 0.0)
 s = solver_registry["hip_dense_primal_normal"]()
 lp.init(s); lp.solve(s)
 ts = []
-for _ in range(5):
+for _ in range(10):
     t = time.perf_counter(); lp.solve(s); ts.append(time.perf_counter() - t)
-print("lp.solve() host-to-host: median %.1f ms -> %.2f M LPs/s (65536 LPs, 67 MB in / 119 MB out over PCIe, pageable memory)"
+print("per call [ms]:", " ".join("%.1f" % (1e3 * t) for t in ts))
+print("lp.solve() host-to-host: median %.1f ms -> %.2f M LPs/s (65536 LPs, 67 MB in / 119 MB out over PCIe)"
       % (1e3 * np.median(ts), 65536 / np.median(ts) / 1e6))
+
+# where the time goes: each stage of the pipeline alone
+def tm(f, n=5):
+    ts = []
+    for _ in range(n):
+        torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    return 1e3 * np.median(ts)
+st = s.buffers["host"]; buf = s.buffers["set0"]
+print("stage b,c into page-locked memory : %.1f ms" % tm(lambda: (np.copyto(st["hb"], lp.b), np.copyto(st["hc"], lp.c))))
+print("upload b,c                        : %.1f ms" % tm(lambda: (st["db"].copy_(st["b"], non_blocking=True), st["dc"].copy_(st["c"], non_blocking=True))))
+print("solve (one launch)                : %.1f ms" % tm(lambda: s.solve_device(st["db"], st["dc"])))
+print("download x,y,z,obj,status,iters   : %.1f ms" % tm(lambda: [st[k].copy_(buf[k], non_blocking=True) for k in ("x", "y", "z", "pobj", "dobj", "status", "iters")]))
+for nc in (1, 2, 4, 8, 16):
+    s.PIPELINE_CHUNKS = nc
+    print("pipeline with %2d chunks           : %.1f ms" % (nc, tm(lambda: lp.solve(s))))
