@@ -48,7 +48,8 @@ typedef struct oracle_opts {
     int max_iter;       /* MAX_ITER                    (primal_normal.cl:9)        */
     int max_refine;     /* refinement passes           (ldl.cl:645)                */
     int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219);
-                           bit3 (8): autoscale -- solve with b/max|b|, c/max|c| and scale the results back */
+                           bit3 (8): autoscale -- solve with b/max|b|, c/max|c| and scale the results back;
+                           bit5 (32): homogeneous self-dual embedding, see hsd_one_raw() */
 } oracle_opts;
 
 void oracle_default_opts(oracle_opts *o) {
@@ -244,9 +245,19 @@ int oracle_solve_primal_normal(int m, int N, const double *A, const double *x, c
  * One LP: max c'x s.t. Ax = b, x >= 0 (equality form, lp.py:306-330), the loop of
  * primal_normal.cl:201-284 with the step of primal_normal.cl:122-156.
  */
-static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+static int ipm_one_path(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                        double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                        work *wk);
+static int hsd_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
                        double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
                        work *wk);
+
+static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                       double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                       work *wk) {
+    return (o->flags & 32) ? hsd_one_raw(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk)
+                           : ipm_one_path(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+}
 
 /* wrapper implementing the optional scaling (not in the reference): b/max|b|, c/max|c| */
 static int ipm_one(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
@@ -274,9 +285,9 @@ static int ipm_one(int m, int N, const double *A, const double *b, const double 
     return st;
 }
 
-static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
-                       double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
-                       work *wk) {
+static int ipm_one_path(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                        double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                        work *wk) {
     int stat = 5;
     if (!(o->flags & 1)) { /* initialize_xzyw, primal_normal.cl:14-28 */
         for (int j = 0; j < N; j++) { x[j] = 1.0; z[j] = 1.0; }
@@ -339,6 +350,160 @@ static int ipm_one_raw(int m, int N, const double *A, const double *b, const dou
         normr0 = normr;
         norms0 = norms;
     }
+    *pobj = po;
+    *dobj = du;
+    *iters = it;
+    if (nrefs) *nrefs = totref;
+    return stat;
+}
+
+/*
+ * The same path on the homogeneous self-dual embedding: the model of the reference's CPU solver
+ * ipo/hsd.c:27-312 (variables x, z, y plus the homogenising pair tau = `phi`, kappa = `psi`) re-derived on the
+ * normal equations so that it reuses gram/factor/forward-backward unchanged:
+ *     A x - b tau = 0,   c tau - A'y + z = 0,   c'x - b'y - kappa = 0,   x, z, tau, kappa >= 0.
+ * With rho = b tau - A x, sigma = c tau - A'y + z, phi = b'y - c'x + kappa, eta = 1 - delta, d = x/z and
+ * r1 = delta mu/x - z + eta sigma, the Newton system reduces to two solves with the same factor,
+ *     M p = A(d c) - b,      M q = A(d r1) - eta rho,       dy = p dtau + q,     dx = u dtau + v,
+ *     u = d (c - A'p),  v = d (r1 - A'q),
+ *     dtau = (eta phi - c'v + b'q + delta mu/tau - kappa) / (|sqrt(d)(c - A'p)|^2 + kappa/tau)
+ * -- the counterpart of hsd.c:222-240, which solves the reduced KKT system twice (fx,fy and gx,gy) and combines
+ * them through dphi.  Differences from hsd.c, all deliberate: a fixed centering delta (hsd.c:133-137 alternates 0
+ * and 1) and step fraction r as on the non-homogeneous path; the stopping rule is the same relative eps on the
+ * tau-scaled residuals as ipm_one_path (hsd.c:156 stops on mu < 1e-12); infeasibility is declared from the
+ * certificate itself -- status 4 when c'x > 0 and |b| tau + |rho| <= 100 eps c'x (x is then a primal ray),
+ * status 2 when b'y < 0 and |c| tau + |sigma| <= 100 eps (-b'y) -- instead of from the signs of the objectives
+ * once mu < 1e-12 (hsd.c:156-177); when both hold the larger certificate wins.  On exit with status 0 (and 5) x, y, z
+ * are divided by tau (hsd.c:266-273); with status 2/4 they are the certificate as it stands.
+ */
+static int hsd_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                       double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                       work *wk) {
+    int stat = 5;
+    double tau = 1.0, kap = 1.0;
+    if (!(o->flags & 1)) {
+        for (int j = 0; j < N; j++) { x[j] = 1.0; z[j] = 1.0; }
+        for (int i = 0; i < m; i++) y[i] = 0.0;
+    } else {
+        double g = 0.0;
+        for (int j = 0; j < N; j++) g += x[j] * z[j];
+        kap = g / N;
+    }
+    double nb = 0.0, nc = 0.0;
+    for (int i = 0; i < m; i++) nb += b[i] * b[i];
+    for (int j = 0; j < N; j++) nc += c[j] * c[j];
+    nb = sqrt(nb); nc = sqrt(nc);
+    const double tol_r = o->eps * (1.0 + nb), tol_s = o->eps * (1.0 + nc), einf = 100.0 * o->eps;
+    const double eta = 1.0 - o->delta;
+    double *p = (double *)malloc(sizeof(double) * (3 * m + 5 * N));
+    double *q = p + m, *e = q + m, *d = e + m, *r1 = d + N, *atp = r1 + N, *dx = atp + N, *dz = dx + N;
+    int it, totref = 0;
+    double po = 0.0, du = 0.0;
+    for (it = 0; it < o->max_iter; it++) {
+        double normr = 0.0, norms = 0.0, gamma = 0.0;
+        for (int i = 0; i < m; i++) {
+            double rho = b[i] * tau;
+            for (int j = 0; j < N; j++) rho -= A[i * N + j] * x[j];
+            wk->rho[i] = rho;
+            normr += rho * rho;
+        }
+        for (int j = 0; j < N; j++) {
+            double sigma = c[j] * tau + z[j];
+            for (int i = 0; i < m; i++) sigma -= A[i * N + j] * y[i];
+            wk->sigma[j] = sigma;
+            norms += sigma * sigma;
+        }
+        normr = sqrt(normr); norms = sqrt(norms);
+        po = 0.0; du = 0.0;
+        for (int j = 0; j < N; j++) { gamma += z[j] * x[j]; po += c[j] * x[j]; }
+        for (int i = 0; i < m; i++) du += b[i] * y[i];
+        if (!(isfinite(normr) && isfinite(norms) && isfinite(gamma) && isfinite(tau) && isfinite(kap))) { stat = 3; break; }
+        if (normr <= tol_r * tau && norms <= tol_s * tau && gamma <= o->eps * tau * (tau + fabs(po))) { stat = 0; break; }
+        const int p_ray = po > 0.0 && nb * tau + normr <= einf * po;
+        const int d_ray = du < 0.0 && nc * tau + norms <= einf * -du;
+        if (p_ray || d_ray) { stat = (p_ray && d_ray) ? (-du > po ? 2 : 4) : (p_ray ? 4 : 2); break; }
+
+        const double mu = (gamma + tau * kap) / (N + 1), dmu = o->delta * mu;
+        const double phi = du - po + kap;
+        for (int k = 0; k < N; k++) {
+            d[k] = x[k] / z[k];
+            r1[k] = dmu / x[k] - z[k] + eta * wk->sigma[k];
+        }
+        gram(m, N, A, d, wk->M);
+        /* the pivot floor (primal_normal.cl:275, 1e-6 absolute) is too coarse here: a dual ray drives z up and the
+         * whole of M = A (x/z) A' down, and nearly-feasible infeasible LPs need pivots of 1e-7 |M| resolved.  This path
+         * uses pivot_floor^2, relative to max|diag M| once that falls below 1. */
+        double mdiag = 0.0;
+        for (int j = 0; j < m; j++) mdiag = fmax(mdiag, fabs(wk->M[j * m + j]));
+        factor(m, wk->M, wk->L, wk->D, o->pivot_floor * o->pivot_floor * fmin(1.0, mdiag));
+        for (int i = 0; i < m; i++) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < N; k++) {
+                s1 += A[i * N + k] * d[k] * c[k];
+                s2 += A[i * N + k] * d[k] * r1[k];
+            }
+            p[i] = s1 - b[i];
+            q[i] = s2 - eta * wk->rho[i];
+        }
+        oracle_forward_backward(m, wk->L, wk->D, p);
+        oracle_forward_backward(m, wk->L, wk->D, q);
+        double den = kap / tau, num = eta * phi + dmu / tau - kap;
+        for (int i = 0; i < m; i++) num += b[i] * q[i];
+        for (int k = 0; k < N; k++) {
+            double ap = 0.0, aq = 0.0;
+            for (int i = 0; i < m; i++) { ap += A[i * N + k] * p[i]; aq += A[i * N + k] * q[i]; }
+            atp[k] = d[k] * (c[k] - ap);           /* u */
+            dx[k] = d[k] * (r1[k] - aq);           /* v */
+            den += atp[k] * (c[k] - ap);
+            num -= c[k] * dx[k];
+        }
+        const double dtau = num / den;
+        for (int i = 0; i < m; i++) wk->dy[i] = p[i] * dtau + q[i];
+        for (int k = 0; k < N; k++) dx[k] += atp[k] * dtau;
+        /* refinement on the x-space residual of  A dx - b dtau = eta rho  (as newton_dy) */
+        const double etol = o->refine_tol * (1.0 + nb) * fmax(tau, kap);
+        int nref = 0;
+        for (;;) {
+            double maxe = 0.0;
+            for (int i = 0; i < m; i++) {
+                double adx = 0.0;
+                for (int k = 0; k < N; k++) adx += A[i * N + k] * dx[k];
+                e[i] = eta * wk->rho[i] + b[i] * dtau - adx;
+                maxe = fmax(maxe, fabs(e[i]));
+            }
+            if (!(maxe > etol) || nref >= o->max_refine) break;
+            oracle_forward_backward(m, wk->L, wk->D, e);
+            for (int i = 0; i < m; i++) wk->dy[i] -= e[i];
+            for (int k = 0; k < N; k++) {
+                double ate = 0.0;
+                for (int i = 0; i < m; i++) ate += A[i * N + k] * e[i];
+                dx[k] += d[k] * ate;
+            }
+            nref++;
+        }
+        totref += nref;
+        int bad = !isfinite(dtau);
+        for (int i = 0; i < m; i++) if (!isfinite(wk->dy[i])) bad = 1;
+        if (bad) { stat = 3; break; }
+        const double dkap = dmu / tau - kap - kap / tau * dtau;
+        double theta = fmax(-dtau / tau, -dkap / kap);
+        theta = fmax(theta, 0.0);
+        for (int j = 0; j < N; j++) {
+            dz[j] = (dmu - z[j] * dx[j]) / x[j] - z[j];
+            theta = fmax(theta, fmax(-dz[j] / z[j], -dx[j] / x[j]));
+        }
+        theta = fmin(o->r / theta, 1.0);
+        for (int i = 0; i < m; i++) y[i] += theta * wk->dy[i];
+        for (int j = 0; j < N; j++) { z[j] += theta * dz[j]; x[j] += theta * dx[j]; }
+        tau += theta * dtau;
+        kap += theta * dkap;
+    }
+    if (stat == 0 || stat == 5) {
+        for (int i = 0; i < m; i++) y[i] /= tau;
+        for (int j = 0; j < N; j++) { x[j] /= tau; z[j] /= tau; }
+        po /= tau; du /= tau;
+    }
+    free(p);
     *pobj = po;
     *dobj = du;
     *iters = it;

@@ -22,6 +22,7 @@ EXPORTS = (
 
 STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
 FLAG_WARM_START, FLAG_WAVE_KERNEL, FLAG_FORCE_GUARD_PATH, FLAG_AUTOSCALE, FLAG_NO_SLACK_PATH = 1, 2, 4, 8, 16
+FLAG_HSD = 32
 
 
 class Opts(ctypes.Structure):

@@ -58,6 +58,7 @@ __device__ __forceinline__ double fast_rcp(double a) {
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
+    asm volatile("" : "+v"(v));   // no fma contraction of the first stage with v's producer: see grp_sum
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
@@ -611,6 +612,7 @@ newton_kernel(int m, int n, long B, const double* __restrict__ pack, const doubl
 }
 
 #include "ipm_group.inc"
+#include "ipm_group_hsd.inc"
 #include "ldl_batched.inc"
 #include "ipm_block.inc"
 
@@ -690,12 +692,12 @@ static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, con
     return hipGetLastError();
 }
 
-template <int MP, int NP, bool SL>
+template <int MP, int NP, bool SL, bool HSD = false>
 static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
                                      double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                      hipStream_t st) {
     using G = GeoG<MP, NP, SL>;
-    int wpb = PYCLLP_WPB;
+    int wpb = HSD ? PYCLLP_WPB_HSD : PYCLLP_WPB;
     while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
     const long per_block = (long)wpb * G::G;
     long blocks = (B + per_block - 1) / per_block;
@@ -704,12 +706,12 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     if (blocks < 1) blocks = 1;
     h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
     h->mp = MP; h->np = NP;
-    hipError_t e = hipFuncSetAttribute((const void*)ipm_group_kernel<MP, NP, SL>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+    auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL>;
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(h->queue, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_group_kernel<MP, NP, SL>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+    hipLaunchKernelGGL(kernel, dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
                        h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, h->queue, o);
     return hipGetLastError();
 }
@@ -732,11 +734,13 @@ struct Variant {
     pack_launch_fn pack;
     solve_launch_fn solve;        // wave-per-LP kernel (first generation)
     solve_launch_fn solve_group;  // group-per-LP kernel (default)
+    solve_launch_fn solve_hsd;    // group-per-LP kernel on the homogeneous self-dual embedding (PYCLLP_FLAG_HSD)
     newton_launch_fn newton;
 };
 
 #define VARIANT(MP, NP) \
-    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP, false>, launch_newton<MP, NP> }
+    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP, false>, \
+      launch_solve_group<MP, NP, false, true>, launch_newton<MP, NP> }
 
 // ordered by cost: the first variant that covers (m, n) is used
 static const Variant kVariants[] = {
@@ -746,11 +750,11 @@ static const Variant kVariants[] = {
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 // slack-aware group kernels: (MP, NP) with NP - MP padded dense columns + the m identity columns
-struct SlackVariant { int mp, np; solve_launch_fn solve_group; };
+struct SlackVariant { int mp, np; solve_launch_fn solve_group, solve_hsd; };
+#define SLACK_VARIANT(MP, NP) { MP, NP, launch_solve_group<MP, NP, true>, launch_solve_group<MP, NP, true, true> }
 static const SlackVariant kSlackVariants[] = {
-    {16, 32, launch_solve_group<16, 32, true>}, {16, 48, launch_solve_group<16, 48, true>},
-    {16, 64, launch_solve_group<16, 64, true>}, {32, 64, launch_solve_group<32, 64, true>},
-    {32, 96, launch_solve_group<32, 96, true>}, {32, 128, launch_solve_group<32, 128, true>},
+    SLACK_VARIANT(16, 32), SLACK_VARIANT(16, 48), SLACK_VARIANT(16, 64), SLACK_VARIANT(32, 64),
+    SLACK_VARIANT(32, 96), SLACK_VARIANT(32, 128),
 };
 static const int kNumSlackVariants = sizeof(kSlackVariants) / sizeof(kSlackVariants[0]);
 
@@ -873,10 +877,14 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
     if ((o.flags & PYCLLP_FLAG_AUTOSCALE) && (o.flags & PYCLLP_FLAG_WAVE_KERNEL))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_AUTOSCALE is not available with PYCLLP_FLAG_WAVE_KERNEL");
+    if ((o.flags & PYCLLP_FLAG_HSD) && (o.flags & PYCLLP_FLAG_WAVE_KERNEL))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_HSD is not available with PYCLLP_FLAG_WAVE_KERNEL");
     const Variant& v = kVariants[h->variant];
-    solve_launch_fn fn = v.solve_group;
+    const bool hsd = (o.flags & PYCLLP_FLAG_HSD) != 0;
+    solve_launch_fn fn = hsd ? v.solve_hsd : v.solve_group;
     if (o.flags & PYCLLP_FLAG_WAVE_KERNEL) fn = v.solve;
-    else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH)) fn = kSlackVariants[h->variant_sl].solve_group;
+    else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH))
+        fn = hsd ? kSlackVariants[h->variant_sl].solve_hsd : kSlackVariants[h->variant_sl].solve_group;
     hipError_t e = fn(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o,
                       (hipStream_t)stream);
     if (e != hipSuccess) return set_err((int)e, "solve kernel launch");
@@ -1040,6 +1048,8 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
+    if (o.flags & PYCLLP_FLAG_HSD)
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve: PYCLLP_FLAG_HSD is provided by the dense solver only");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
     HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));

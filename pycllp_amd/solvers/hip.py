@@ -29,13 +29,18 @@ class HipDensePrimalNormalSolver(BaseSolver):
     (callers use ``StandardLP.to_equality_form()`` first, as for the OpenCL solver)."""
     name = 'hip_dense_primal_normal'
 
-    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale=False, **options):
-        """``autoscale=True`` (PYCLLP_FLAG_AUTOSCALE, not in the reference) solves every LP with b/max|b| and c/max|c| and
+    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale=False, hsd=False, **options):
+        """``hsd=True`` (PYCLLP_FLAG_HSD) solves on the homogeneous self-dual embedding, the model of the reference's
+        CPU solver ``pycllp/ipo/hsd.c``: infeasible (status 2) and unbounded (status 4) LPs are then detected reliably,
+        after ~12-15 iterations, and ``x`` / ``y, z`` hold the certificate.
+        ``autoscale=True`` (PYCLLP_FLAG_AUTOSCALE, not in the reference) solves every LP with b/max|b| and c/max|c| and
         scales the results back: use it when b or c are orders of magnitude away from 1.  Other keyword arguments are
         the fields of ``pycllp_hip_opts`` (eps, delta, r, pivot_floor, refine_tol, max_iter, max_refine, flags)."""
         super(HipDensePrimalNormalSolver, self).__init__()
         if autoscale:
             options["flags"] = int(options.get("flags", 0)) | _native.FLAG_AUTOSCALE
+        if hsd:
+            options["flags"] = int(options.get("flags", 0)) | _native.FLAG_HSD
         self.device = device
         self.stream = stream
         self.keep_on_device = keep_on_device

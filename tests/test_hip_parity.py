@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, rel_err
+from conftest import golden, rel_err, status_cases, check_certificates
 from pycllp_amd import problems
 from pycllp_amd.lp import SparseMatrix, EqualityLP, StandardLP
 from pycllp_amd.solvers import solver_registry
@@ -316,6 +316,68 @@ def test_alternative_kernel_paths_agree_with_oracle(flags, what, m, n):
     assert (s.status == 0).all()
     assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and (s.iters == r["iters"]).mean() > 0.99
     assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+
+
+# ---- homogeneous self-dual embedding (PYCLLP_FLAG_HSD) -----------------------------------------------------
+
+def test_hsd_statuses_against_reference_highs_and_oracle():
+    """Mixed-sign LPs, most of them infeasible or unbounded (tests/golden/status_cases.npz: statuses of the reference's
+    hsd.c and of HiGHS): the HSD kernel must report the true status for every LP, agree with the oracle restatement
+    LP by LP, match the reference's objectives on the optimal ones and return valid certificates."""
+    for A, b, c, ref_status, highs, ref_pobj in status_cases():
+        elp, s = solve_arrays(A, b, c, hsd=True)
+        np.testing.assert_array_equal(s.status, highs)
+        right = ref_status == highs
+        np.testing.assert_array_equal(s.status[right], ref_status[right])
+        r = oracle_on(elp, flags=32)
+        np.testing.assert_array_equal(s.status, r["status"])
+        assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+        opt = highs == 0
+        if opt.any():
+            assert rel_err(s.primal_obj[opt], ref_pobj[opt]).max() < OBJ_TOL
+            assert rel_err(s.primal_obj[opt], r["pobj"][opt]).max() < 1e-9
+        check_certificates(elp.A.todense(), elp.b, elp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
+
+
+@pytest.mark.parametrize("m,n", [(16, 32), (32, 64)])
+@pytest.mark.parametrize("flags", [0, 16, 4, 8])
+def test_hsd_objective_parity_on_baseline_configs(m, n, flags):
+    """The HSD kernel on the BASELINE shapes -- slack-aware and generic (16) variants, guarded LDL' path (4),
+    autoscale (8) -- against the reference goldens (1e-8) and the oracle (1e-9, same iteration counts)."""
+    g = golden("config_%dx%d.npz" % (m, n))
+    A, b, c = problems.random_dense_arrays(m, n, int(g["nobj"]), seed=0)
+    elp, s = solve_arrays(A, b, c, hsd=True, flags=flags)
+    assert (s.status == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    r = oracle_on(elp, flags=32 | (flags & 8))
+    # the kernel carries rho from step to step, the oracle recomputes it: a stop test that lands within rounding of
+    # its threshold may fall one iteration apart
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and (s.iters == r["iters"]).mean() > 0.97
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    nfull = g["x"].shape[0]
+    np.testing.assert_allclose(s.x[:nfull, :n], g["x"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (2, 3), (17, 40), (32, 96), (5, 123)])
+def test_hsd_shapes_up_to_the_maximum(m, n):
+    rs = np.random.RandomState(m * 131 + n)
+    A = rs.rand(m, n) * 2 - 0.4
+    b = rs.rand(96, m) * 2 - 0.3; c = rs.rand(96, n) * 2 - 0.4
+    lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)       # general dense A: no slack columns
+    s = solver_registry["hip_dense_primal_normal"](hsd=True)
+    lp.init(s); lp.solve(s)
+    r = oracle_on(lp, flags=32)
+    np.testing.assert_array_equal(s.status, r["status"])
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    opt = s.status == 0
+    if opt.any():
+        assert rel_err(s.primal_obj[opt], r["pobj"][opt]).max() < 1e-8
+
+
+def test_hsd_flag_is_rejected_where_it_is_not_implemented():
+    A, b, c = problems.random_dense_arrays(8, 12, 4, seed=1)
+    with pytest.raises(ValueError):
+        solve_arrays(A, b, c, hsd=True, flags=2)
 
 
 def test_keep_on_device_returns_cuda_tensors():

@@ -7,7 +7,7 @@ own tests (tests/test_vanderbei.py:42 rtol=atol=1e-6; tests/helpers.py:97-102 rt
 import numpy as np
 import pytest
 
-from conftest import golden, rel_err
+from conftest import golden, rel_err, status_cases, check_certificates
 from pycllp_amd import problems
 
 OBJ_TOL = 1e-8
@@ -135,6 +135,36 @@ def test_status_codes_infeasible_unbounded(oracle_port):
     # unbounded: max x1 s.t. x1 - x2 = 0
     r = oracle_port.dense_solve(np.array([[1.0, -1.0]]), np.array([[0.0]]), np.array([[1.0, 0.0]]))
     assert r["status"][0] != 0
+
+
+def test_hsd_embedding_statuses_against_reference_and_highs(oracle_port):
+    """flags=32 (homogeneous self-dual embedding) on the mixed-sign fixture: the status must be the true
+    one (HiGHS verdict stored in the fixture) for every LP, equal to the reference hsd.c status wherever that one is
+    right, objectives of the optimal LPs within 1e-8 of the reference, certificates valid."""
+    agree = total = 0
+    for A, b, c, ref_status, highs, ref_pobj in status_cases():
+        Ae, be, ce = problems.equality_arrays(A, b, c)
+        r = oracle_port.dense_solve(Ae, be, ce, nthreads=4, flags=32)
+        np.testing.assert_array_equal(r["status"], highs)
+        right = ref_status == highs
+        np.testing.assert_array_equal(r["status"][right], ref_status[right])
+        opt = highs == 0
+        assert rel_err(r["pobj"][opt], ref_pobj[opt]).max() < OBJ_TOL if opt.any() else True
+        assert r["iters"].max() < 60
+        check_certificates(Ae, be, ce, r)
+        agree += int(right.sum()); total += len(highs)
+    assert agree >= total - 8      # the reference mislabels a handful of unbounded LPs as infeasible (fixture docstring)
+
+
+@pytest.mark.parametrize("m,n", [(16, 32), (32, 64)])
+def test_hsd_embedding_objective_parity_on_baseline_configs(oracle_port, m, n):
+    g = golden("config_%dx%d.npz" % (m, n))
+    A, b, c = problems.random_dense_arrays(m, n, int(g["nobj"]), seed=0)
+    Ae, be, ce = problems.equality_arrays(A, b[:512], c[:512])
+    r = oracle_port.dense_solve(Ae, be, ce, nthreads=4, flags=32)
+    assert (r["status"] == 0).all()
+    assert rel_err(r["pobj"], g["pobj"][:512]).max() < OBJ_TOL
+    assert rel_err(r["dobj"], g["dobj"][:512]).max() < OBJ_TOL
 
 
 def test_sparse_config_objective_parity(oracle_port):

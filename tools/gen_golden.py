@@ -139,6 +139,32 @@ def baseline_sparse(m=128, n=256, density=0.025, nlp=64):
     print("sparse config (%d,%d,%.3f): nnz %d, status" % (m, n, density, A.nnz), np.bincount(g["status"]), "max gap", gap.max())
 
 
+def status_cases(nshape=8, nlp=32):
+    """Mixed-sign random LPs, most of them infeasible or unbounded: inputs, the status the reference's HSD solver
+    reports (ipo/hsd.c:156-177: 0 optimal, 2 primal infeasible, 4 dual infeasible) and, as an independent arbiter,
+    the verdict of scipy's HiGHS (0 optimal, 2 infeasible, 4 unbounded).  hsd.c decides between 2 and 4 from the sign of
+    b'y alone once mu < 1e-12, which mislabels some unbounded LPs as primal infeasible -- HiGHS settles those."""
+    from scipy.optimize import linprog
+    rs = np.random.RandomState(20241004)
+    out = dict(nshape=nshape)
+    tot = {}
+    for k in range(nshape):
+        m = int(rs.randint(3, 33)); n = int(rs.randint(3, 64))
+        A = rs.rand(m, n) * 2 - (1.0, 0.3, 0.05)[k % 3]
+        A[rs.rand(m, n) < 0.5 * rs.rand()] = 0.0
+        b = rs.rand(nlp, m) * 2 - (0.7, 0.2, 0.2)[k % 3]
+        c = rs.rand(nlp, n) * 2 - (0.7, 0.3, 0.3)[k % 3]
+        g = hsd(A, b, c)
+        hi = np.array([{0: 0, 2: 2, 3: 4}.get(linprog(-c[i], A_ub=A, b_ub=b[i], bounds=(0, None), method="highs").status, -1)
+                       for i in range(nlp)], dtype=np.int8)
+        out.update({"A%d" % k: A, "b%d" % k: b, "c%d" % k: c, "status%d" % k: g["status"].astype(np.int8),
+                    "pobj%d" % k: g["pobj"], "dobj%d" % k: g["dobj"], "highs%d" % k: hi})
+        for a, h in zip(g["status"], hi):
+            tot[(int(a), int(h))] = tot.get((int(a), int(h)), 0) + 1
+    np.savez_compressed(os.path.join(OUT, "status_cases.npz"), **out)
+    print("status cases (reference hsd.c status, HiGHS verdict): count", tot)
+
+
 if __name__ == "__main__":
     if not hsd_ref.available():
         sys.exit("oracle/_ref/libhsd_ref.so missing: run `make -C oracle` in the container that has /root/reference")
@@ -150,3 +176,4 @@ if __name__ == "__main__":
     baseline_config(16, 32)
     baseline_config(32, 64)
     baseline_sparse()
+    status_cases()
