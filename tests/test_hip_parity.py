@@ -339,6 +339,24 @@ def test_hsd_statuses_against_reference_highs_and_oracle():
         check_certificates(elp.A.todense(), elp.b, elp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
 
 
+def test_hsd_slowly_collapsing_infeasible_lps_at_the_baseline_shape():
+    """(32, 64) batch with mixed-sign A, b, c: ~94 % primal infeasible, some of them only after 30-50 iterations with x
+    shrinking to 1e-13 (a kernel that carried rho = b tau - A x from step to step instead of recomputing it lost 0.4 %
+    of these to the iteration limit).  Statuses and iteration counts must be the oracle's."""
+    rs = np.random.RandomState(11)
+    A = rs.rand(32, 64) * 2 - 0.3
+    b = rs.rand(65536, 32) * 2 - 0.2; c = rs.rand(65536, 64) * 2 - 0.3
+    pick = np.r_[0:1024, [270, 356, 394, 516, 839, 1006, 1187, 1312, 1588, 1806, 1976, 2166, 3502, 3587, 4136, 4540]]
+    elp, s = solve_arrays(A, b[pick], c[pick], hsd=True)
+    r = oracle_on(elp, flags=32)
+    np.testing.assert_array_equal(s.status, r["status"])
+    assert set(np.unique(s.status)) <= {0, 2} and (s.status == 2).mean() > 0.9
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and s.iters.max() < 80
+    opt = s.status == 0
+    assert rel_err(s.primal_obj[opt], r["pobj"][opt]).max() < 1e-9
+    check_certificates(elp.A.todense(), elp.b, elp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
+
+
 @pytest.mark.parametrize("m,n", [(16, 32), (32, 64)])
 @pytest.mark.parametrize("flags", [0, 16, 4, 8])
 def test_hsd_objective_parity_on_baseline_configs(m, n, flags):
@@ -350,8 +368,8 @@ def test_hsd_objective_parity_on_baseline_configs(m, n, flags):
     assert (s.status == 0).all()
     assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
     r = oracle_on(elp, flags=32 | (flags & 8))
-    # the kernel carries rho from step to step, the oracle recomputes it: a stop test that lands within rounding of
-    # its threshold may fall one iteration apart
+    # ~1.5 % of the LPs stop one iteration apart: on this path all three residuals shrink in lockstep, so the stop
+    # test often lands within rounding (summation order) of its threshold
     assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and (s.iters == r["iters"]).mean() > 0.97
     assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
     nfull = g["x"].shape[0]
