@@ -5,7 +5,9 @@
  * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every pointer argument
  * named *_dev is a DEVICE pointer owned by the caller (the Python host passes torch tensors'
  * data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point
- * synchronises the host with the device except where stated; all of them are re-entrant per handle.
+ * synchronises the host with the device except where stated; all of them are re-entrant per handle: solves
+ * may be issued from several host threads and on several streams with one handle (up to 64 launches in flight;
+ * the caller keeps their output buffers apart).
  * Return value: 0 on success, a negative PYCLLP_E_* code for argument errors, or a positive
  * hipError_t for runtime failures (pycllp_hip_last_error() gives the text).
  *

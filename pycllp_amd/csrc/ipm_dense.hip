@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -633,11 +634,15 @@ static int set_err(int code, const char* what) {
         if (e_ != hipSuccess) return set_err((int)e_, #expr);     \
     } while (0)
 
+static constexpr unsigned kQueueRing = 64;   // work-queue counters per handle = launches that may be in flight at once
+
 struct pycllp_hip_dense {
     int m, n, mp, np, variant;
     double* pack;
     double* a_rm;   // row-major copy of A [m,n] for the group kernel
-    int* queue;     // device work-queue head of the group kernel (zeroed before every launch)
+    int* queue;     // device work-queue heads of the group kernel: a ring of kQueueRing counters, one per launch in flight,
+                    // so that solves issued on different streams with the same handle do not share a counter
+    std::atomic<unsigned> qnext;
     int variant_sl; // index into kSlackVariants when the last m columns of A are the identity, else -1
     int grid, block, lds;
     int num_cu;
@@ -709,10 +714,11 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL>;
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(h->queue, 0, sizeof(int), st);
+    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
+    e = hipMemsetAsync(qhead, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
-                       h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, h->queue, o);
+                       h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, qhead, o);
     return hipGetLastError();
 }
 
@@ -778,7 +784,8 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
 struct pycllp_hip_sparse {
     BlockA desc;
     void* dev_blob;     // one allocation holding every device array of desc
-    int* queue;
+    int* queue;         // ring of kQueueRing work-queue heads (see pycllp_hip_dense)
+    std::atomic<unsigned> qnext;
     int lds, num_cu, grid;
 };
 
@@ -838,7 +845,7 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
     if (e != hipSuccess) { free(h); return set_err((int)e, "hipMalloc(pack)"); }
     e = hipMalloc((void**)&h->a_rm, sizeof(double) * (size_t)m * n);
     if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "hipMalloc(A)"); }
-    e = hipMalloc((void**)&h->queue, sizeof(int));
+    e = hipMalloc((void**)&h->queue, sizeof(int) * kQueueRing);
     if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); free(h); return set_err((int)e, "hipMalloc(queue)"); }
     hipStream_t st = (hipStream_t)stream;
     e = hipMemcpyAsync(h->a_rm, A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, st);
@@ -1006,7 +1013,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
                                         term_col.size()) + 16 * 12;
     std::vector<char> host(total);
     e = hipMalloc(&h->dev_blob, total);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->queue, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->queue, sizeof(int) * kQueueRing);
     if (e != hipSuccess) { if (h->dev_blob) (void)hipFree(h->dev_blob); free(h); return set_err((int)e, "hipMalloc(sparse A)"); }
     size_t off = 0;
     char* db = (char*)h->dev_blob;
@@ -1052,13 +1059,14 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
         return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve: PYCLLP_FLAG_HSD is provided by the dense solver only");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
-    HIP_TRY(hipMemsetAsync(h->queue, 0, sizeof(int), st));
+    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
+    HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     long blocks = (long)h->num_cu * per_cu;
     if (blocks > B) blocks = B;
     h->grid = (int)blocks;
     hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
-                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, h->queue, o);
+                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, o);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
     return 0;

@@ -218,6 +218,28 @@ def test_host_pipeline_equals_device_resident_solve():
     np.testing.assert_array_equal(s.x, host["x"])
 
 
+def test_concurrent_solves_on_two_streams_share_one_handle():
+    """The C ABI is re-entrant per handle: two solves in flight on different streams (each with its own work-queue
+    counter and its own output buffers) must both give what a lone solve gives."""
+    A, b, c = problems.random_dense_arrays(16, 32, 6000, seed=21)
+    elp, s = solve_arrays(A, b, c)
+    ref = np.array(s.primal_obj)
+    bd = torch.as_tensor(elp.b, device="cuda"); cd = torch.as_tensor(elp.c, device="cuda")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(4):
+        for k, st in enumerate((s1, s2)):
+            s.stream = st
+            half = slice(0, 3000) if k == 0 else slice(3000, 6000)
+            st.wait_stream(torch.cuda.current_stream())
+            outs.append((half, s.solve_device(bd[half], cd[half], slot=10 + 2 * rep + k)))
+    torch.cuda.synchronize()
+    s.stream = None
+    for half, buf in outs:
+        np.testing.assert_array_equal(buf["pobj"].cpu().numpy(), ref[half])
+        assert int((buf["status"] != 0).sum()) == 0
+
+
 def test_empty_batch():
     A = np.random.RandomState(0).rand(4, 6)
     lp = StandardLP(SparseMatrix(matrix=A), np.zeros((0, 4)), np.zeros((0, 6)), np.zeros(0)).to_equality_form()
