@@ -19,8 +19,8 @@
  * _ldl.pyx) disagree follow SURVEY.md section 8(a) "divergence" table:
  *   - stopping rule: RELATIVE eps on |rho|, |sigma|, gamma (reference: absolute
  *     EPS 1e-7f, primal_normal.cl:8,256) -- required to reach 1e-8 objective parity
- *     with ipo.py; the 10x growth exits (primal_normal.cl:261-269) are kept with the
- *     same relative floor;
+ *     with ipo.py; the 10x growth exits (primal_normal.cl:261-269) are kept, with the
+ *     reference's floor (1e-7 absolute = 1e3 x the relative tolerance for |b| ~ 1);
  *   - centering DELTA=0.02, mu = delta*gamma/(n+m) (primal_normal.cl:10,272);
  *   - step: theta starts at 0 so the step is clamped to <=1 (primal_normal.cl:134,143);
  *   - beta = sqrt(max |diag M|) (ldl.cl:280-294);
@@ -327,8 +327,10 @@ static int ipm_one_path(int m, int N, const double *A, const double *b, const do
 
         if (!(isfinite(normr) && isfinite(norms) && isfinite(gamma))) { stat = 3; break; }
         if (normr <= tol_r && norms <= tol_s && gamma <= o->eps * (1.0 + fabs(po))) { stat = 0; break; }
-        if (normr > 10 * normr0 && normr > tol_r) { stat = 2; break; }
-        if (norms > 10 * norms0 && norms > tol_s) { stat = 4; break; }
+        /* growth exits with the reference's own floor: EPS = 1e-7f absolute (primal_normal.cl:8,261-269) = 1e3 x the
+         * relative stopping tolerance used here, for |b|, |c| ~ 1 */
+        if (normr > 10 * normr0 && normr > 1e3 * tol_r) { stat = 2; break; }
+        if (norms > 10 * norms0 && norms > 1e3 * tol_s) { stat = 4; break; }
 
         double mu = o->delta * gamma / (N + m); /* primal_normal.cl:272 */
         totref += newton_dy(m, N, A, x, z, y, b, c, mu, o, wk);

@@ -35,6 +35,11 @@
 
 #include "../../include/pycllp_hip.h"
 
+// The 10x-growth exits (primal_normal.cl:261-269) keep the reference's own floor -- EPS = 1e-7f absolute, which is
+// 1e3 x the relative stopping tolerance used here (for |b|, |c| ~ 1) -- instead of the stopping tolerance itself:
+// within a factor 1000 of convergence a residual is rounding noise, and a 10x bump of noise is not divergence.
+#define PYCLLP_GROWTH_FLOOR 1e3
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define WAVE 64
@@ -512,8 +517,8 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
 
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
             if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; break; }
-            if (normr > 10.0 * normr0 && normr > tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; break; }
-            if (norms > 10.0 * norms0 && norms > tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; break; }
+            if (normr > 10.0 * normr0 && normr > PYCLLP_GROWTH_FLOOR * tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; break; }
+            if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; break; }
             if (__any(!isfinite(dy))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
 
             // step (primal_normal.cl:122-156)

@@ -6,8 +6,8 @@ from pycllp_amd import problems, _native
 from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry
 NPHASE = 10
-names = ["0 A'y, sigma, reductions", "1 staging, zero M, A x, Gram assembly, A d t", "2 rhs, beta", "3 LDL'", "4 solve (wave 0)",
-         "5 A'dy, dx", "6 refinement check (+passes)", "7 tests + step", "8 -", "9 load/store LP"]
+names = ["0 A'y, sigma, reductions", "1 staging, zero M, A x, Gram assembly, A d t", "2 rhs, beta", "3 LDL': barriers + trailing update (MFMA)", "4 solve (wave 0)",
+         "5 A'dy, dx", "6 refinement check (+passes)", "7 tests + step", "8 LDL': diagonal block + panel (wave 0)", "9 load/store LP"]
 m, n, B = 128, 256, 4096
 A, b, c = problems.random_sparse_arrays(m, n, B, density=0.025, seed=0)
 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
