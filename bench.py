@@ -78,10 +78,19 @@ def main():
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
     ap.add_argument("--sync-gather", action="store_true", help="block on the result gather after every solve (no overlap)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="development aid: take the multi-rank code path (process group, result gather, barriers) even "
+                         "with one rank -- exercises the RCCL calls on a one-GPU box")
     ap.add_argument("--rehearse", action="store_true",
                     help="development aid: run the N-rank path on ONE GPU (all ranks share cuda:0, gloo backend, "
                          "results gathered through host memory); the numbers it prints are not benchmark results")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON result of rank 0.  Libraries write there too (RCCL prints a five-line
+    # version banner to stdout when its communicator comes up), so file descriptor 1 is pointed at stderr for the whole
+    # run and the result goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -103,7 +112,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.rehearse else dev     # where collectives run
-    if world > 1:
+    multi = world > 1 or args.force_collectives
+    if multi:
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -146,7 +156,7 @@ def main():
     # solve: outputs are double-buffered (slot k%2), receive buffers on rank 0 too, and a slot is reused only after the
     # gather that read it has completed.  --sync-gather falls back to a blocking gather after every solve.
     recv = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "x": (B, Nn), "y": (B, m_)}
         dts = {"status": torch.int32, "iters": torch.int32}
         recv = [{f: [torch.empty(shapes[f], dtype=dts.get(f, torch.float64), device=cdev) for _ in range(world)]
@@ -167,7 +177,7 @@ def main():
         buf = solver.solve_device(bd, cd, slot=sl)     # the dominant kernel, on torch's current stream
         if e1 is not None:
             e1.record()
-        if world > 1:
+        if multi:
             works = []
             for f in fields:
                 t = buf[f].to(cdev) if args.rehearse else buf[f]
@@ -186,7 +196,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -197,12 +207,12 @@ def main():
     wait_slot(0); wait_slot(1)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     gathered = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         last = (args.steps - 1) % 2
         gathered = {f: torch.cat(recv[last][f], dim=0) for f in fields}
 
@@ -212,7 +222,7 @@ def main():
     pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
     ok_local = int((status == 0).sum())
     gap = float(np.max(np.abs(pobj - dobj) / np.maximum(1.0, np.abs(pobj))))
-    if world > 1:
+    if multi:
         agg = torch.tensor([ok_local, float(iters.sum())], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg)
         ok_total, iters_mean = int(agg[0].item()), float(agg[1].item()) / (B * world)
@@ -292,8 +302,9 @@ def main():
                                              "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": bytes_per_lp(M, Nn)}},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.destroy_process_group()
 
 
