@@ -67,6 +67,21 @@ def cpu_baseline(seconds=12.0):
                       "(the C solver keeps global state: not thread-safe)" % (done, dt)}
 
 
+def cpu_port_all_cores(nlp=32768):
+    """The oracle restatement (same algorithm as the kernel, OpenMP over LPs) on every host core: the all-core figure of
+    SURVEY 8d, reported NEXT TO cpu_baseline (the reference solver itself cannot use threads)."""
+    from oracle import port
+    from pycllp_amd import problems
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    A, b, c = problems.random_dense_arrays(M, N_STD, nlp, seed=0)
+    Ae, be, ce = problems.equality_arrays(A, b, c)
+    port.dense_solve(Ae, be[:256], ce[:256], nthreads=cores)
+    t = time.perf_counter(); r = port.dense_solve(Ae, be, ce, nthreads=cores); dt = time.perf_counter() - t
+    assert (r["status"] == 0).all()
+    return {"value": nlp / dt, "unit": "LPs/s", "cores": cores, "kind": "port",
+            "sample": "first %d LPs of the workload, oracle/ipm_dense_ref.c with OpenMP on %d threads, %.1f s" % (nlp, cores, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,9 +134,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cpu = None
+    cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        cpu_all = cpu_port_all_cores()
 
     B = args.batch
     sparse = args.workload == "sparse5"
@@ -301,6 +317,7 @@ def main():
                          "hbm_algorithmic": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                              "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": bytes_per_lp(M, Nn)}},
             "cpu_baseline": cpu,
+            "cpu_port_all_cores": cpu_all,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
