@@ -1060,8 +1060,6 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
-    if (o.flags & PYCLLP_FLAG_HSD)
-        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve: PYCLLP_FLAG_HSD is provided by the dense solver only");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
     int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);

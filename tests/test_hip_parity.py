@@ -553,6 +553,40 @@ def test_sparse_config5_against_golden_objectives():
     np.testing.assert_allclose(s.y[:16], g["y"], rtol=1e-5, atol=1e-6)
 
 
+def test_sparse_solver_hsd_statuses_and_certificates():
+    """PYCLLP_FLAG_HSD through the sparse (one LP per workgroup) kernel: the mixed-sign fixture again -- true status for
+    every LP, the oracle's answer LP by LP, valid certificates."""
+    for A, b, c, ref_status, highs, ref_pobj in status_cases():
+        lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+        s = solver_registry["hip_sparse_primal_normal"](hsd=True)
+        lp.init(s); lp.solve(s)
+        np.testing.assert_array_equal(s.status, highs)
+        r = oracle_on(lp, flags=32)
+        np.testing.assert_array_equal(s.status, r["status"])
+        assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+        opt = highs == 0
+        if opt.any():
+            assert rel_err(s.primal_obj[opt], ref_pobj[opt]).max() < OBJ_TOL
+            assert rel_err(s.primal_obj[opt], r["pobj"][opt]).max() < 1e-9
+        check_certificates(lp.A.todense(), lp.b, lp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
+
+
+@pytest.mark.parametrize("flags", [0, 4, 8])
+def test_sparse_solver_hsd_config5_golden_objectives(flags):
+    import scipy.sparse as sp
+    g = golden("config_sparse_128x256.npz")
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(int(g["m"]), int(g["n"])))
+    lp = StandardLP(SparseMatrix(matrix=A), g["b"], g["c"], 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](hsd=True, flags=flags)
+    lp.init(s)
+    st = lp.solve(s)
+    assert (st == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    r = oracle_on(lp, flags=32 | (flags & 8))
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    np.testing.assert_allclose(s.x[:16, :int(g["n"])], g["x"], rtol=1e-5, atol=1e-6)
+
+
 # ---- autoscale option (not in the reference) -------------------------------------------------------------------------
 
 @pytest.mark.parametrize("kind", ["dense", "sparse"])

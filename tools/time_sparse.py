@@ -9,7 +9,7 @@ m, n, B = 128, 256, int(os.environ.get("SP_B", 16384))
 dens = float(os.environ.get("SP_DENSITY", 0.025))
 A, b, c = problems.random_sparse_arrays(m, n, B, density=dens, seed=0)
 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
-s = solver_registry["hip_sparse_primal_normal"]()
+s = solver_registry["hip_sparse_primal_normal"](hsd=bool(int(os.environ.get("SP_HSD", "0"))))
 lp.init(s)
 be = torch.as_tensor(b, device="cuda")
 ce = torch.as_tensor(np.hstack([c, np.zeros((B, m))]), device="cuda")
