@@ -28,6 +28,7 @@ for path in sys.argv[1:]:
     assert L.pycllp_hip_dense_init(m, N, vp(Ad.data_ptr()), None, ctypes.byref(h)) == 0
     o = _native.Opts(); L.pycllp_hip_default_opts(ctypes.byref(o)); o.flags = flags
     if os.environ.get("AB_PIVOT_FLOOR"): o.pivot_floor = float(os.environ["AB_PIVOT_FLOOR"])
+    if os.environ.get("AB_R"): o.r = float(os.environ["AB_R"])
     libs.append((path, L, h, o))
 
 def run(L, h, o):
