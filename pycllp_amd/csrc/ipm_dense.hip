@@ -711,7 +711,9 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
     const long per_block = (long)wpb * G::G;
     long blocks = (B + per_block - 1) / per_block;
-    const long resident = (long)h->num_cu * ((size_t)h->max_lds / G::lds_bytes(wpb) >= 2 ? 2 : 1);
+    // one persistent workgroup per CU: its 8 waves (4 for the HSD kernel, compiled for 512 registers) already use the
+    // whole register file, so a second workgroup could not become resident whatever the LDS says
+    const long resident = (long)h->num_cu;
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
