@@ -707,7 +707,7 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
                                      double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                      hipStream_t st) {
     using G = GeoG<MP, NP, SL>;
-    int wpb = HSD ? PYCLLP_WPB_HSD : PYCLLP_WPB;
+    int wpb = HSD ? hsd_wpb<MP>() : PYCLLP_WPB;
     while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
     const long per_block = (long)wpb * G::G;
     long blocks = (B + per_block - 1) / per_block;
