@@ -8,6 +8,9 @@ from pycllp_amd.solvers import solver_registry
 from oracle import port
 
 rs = np.random.RandomState(int(os.environ.get("FUZZ_SEED", 1)))
+HSD = bool(int(os.environ.get("FUZZ_HSD", "0")))     # FUZZ_HSD=1: every solve with PYCLLP_FLAG_HSD, oracle flags=32
+SIGNED = bool(int(os.environ.get("FUZZ_SIGNED", "0")))  # mixed-sign A, b, c (infeasible / unbounded LPs; use with HSD)
+OFL = 32 if HSD else 0
 rel = lambda a, r: np.abs(a - r) / np.maximum(1.0, np.abs(r))
 bad = 0
 
@@ -31,20 +34,23 @@ for t in range(int(os.environ.get("FUZZ_N", 24))):
     # invariant; far-off scalings converge slowly and chaotically in BOTH implementations
     sb, sc = 10.0 ** rs.randint(-1, 2), 10.0 ** rs.randint(-1, 2)
     b = sb * (0.5 + rs.rand(B, m)); c = sc * (0.5 + rs.rand(B, n))
+    if SIGNED:
+        A = (rs.rand(m, n) * 2 - rs.choice([1.0, 0.3, 0.05])) * (rs.rand(m, n) < rs.choice([1.0, 0.5]))
+        b = rs.rand(B, m) * 2 - rs.choice([0.7, 0.2]); c = rs.rand(B, n) * 2 - rs.choice([0.7, 0.3])
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
-    s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
-    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    s = solver_registry["hip_dense_primal_normal"](hsd=HSD); lp.init(s); st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8, flags=OFL)
     check("dense m=%d n=%d B=%d scale b %.0e c %.0e" % (m, n, B, sb, sc), s, st, r)
 
 # dense: rank-deficient A (duplicated rows), equality LPs with mixed-sign A
 A = rs.rand(6, 14); A = np.vstack([A, A[:3]]); b = 0.5 + rs.rand(40, 6); b = np.hstack([b, b[:, :3]]); c = 0.5 + rs.rand(40, 14)
 lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
-s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
-check("dense duplicated rows (rank deficient)", s, st, port.dense_solve(lp.A.todense(), lp.b, lp.c))
+s = solver_registry["hip_dense_primal_normal"](hsd=HSD); lp.init(s); st = lp.solve(s)
+check("dense duplicated rows (rank deficient)", s, st, port.dense_solve(lp.A.todense(), lp.b, lp.c, flags=OFL))
 A = rs.randn(10, 30); x0 = rs.rand(64, 30) + 0.1; b = x0 @ A.T; y0 = rs.randn(64, 10); c = y0 @ A - (rs.rand(64, 30) + 0.1)
 lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)
-s = solver_registry["hip_dense_primal_normal"](); lp.init(s); st = lp.solve(s)
-check("equality LP, mixed-sign A, strictly feasible pair", s, st, port.dense_solve(A, b, c))
+s = solver_registry["hip_dense_primal_normal"](hsd=HSD); lp.init(s); st = lp.solve(s)
+check("equality LP, mixed-sign A, strictly feasible pair", s, st, port.dense_solve(A, b, c, flags=OFL))
 
 # sparse, random shapes
 for t in range(int(os.environ.get("FUZZ_NS", 8))):
@@ -52,7 +58,7 @@ for t in range(int(os.environ.get("FUZZ_NS", 8))):
     dens = float(rs.choice([0.02, 0.05, 0.2]))
     A, b, c = problems.random_sparse_arrays(m, n, B, density=max(dens, 3.0 / n), seed=int(rs.randint(1 << 30)))
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
-    s = solver_registry["hip_sparse_primal_normal"](); lp.init(s); st = lp.solve(s)
-    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
+    s = solver_registry["hip_sparse_primal_normal"](hsd=HSD); lp.init(s); st = lp.solve(s)
+    r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8, flags=OFL)
     check("sparse m=%d n=%d B=%d density %.2f nnz %d" % (m, n, B, dens, A.nnz), s, st, r)
 print("mismatches:", bad)
