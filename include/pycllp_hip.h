@@ -62,7 +62,7 @@ extern "C" {
                               and unbounded LPs end with a certificate after ~12-15 iterations -- status 2 with (y, z):
                               b'y < 0, A'y - z ~ 0; status 4 with x: c'x > 0, A x ~ 0 -- instead of through the
                               heuristic 10x-growth exits.  x, y, z of a status 2/4 LP are the certificate in homogeneous
-                              scaling.  The LDL' pivot floor on this path is pivot_floor^2 * min(1, max|diag M|).
+                              scaling.  The LDL' pivot floor of column j on this path is pivot_floor^2 * |M_jj| (own original diagonal).
                               Dense and sparse solvers; not available with PYCLLP_FLAG_WAVE_KERNEL.                */
 #define PYCLLP_FLAG_NO_SLACK_PATH 16 /* do not use the slack-aware kernel even when the last m columns of A are the
                                         identity (diagnostic: results must agree to rounding)                    */

@@ -83,8 +83,10 @@ void oracle_ldl(int n, const double *A, double *L, double *D) {
     }
 }
 
-/* modified LDL' (Nocedal & Wright alg. 3.4 diagonal guard), ldl.cl:57-107 */
-void oracle_modified_ldl(int n, const double *A, double *L, double *D, double beta, double delta) {
+/* modified LDL' (Nocedal & Wright alg. 3.4 diagonal guard), ldl.cl:57-107.  The pivot floor of column j is
+ * max(delta, delta_rel |A_jj|): the reference has the absolute delta only (delta_rel = 0); the homogeneous self-dual
+ * path uses a floor relative to each pivot's own original diagonal entry instead (see hsd_one_raw). */
+static void modified_ldl_core(int n, const double *A, double *L, double *D, double beta, double delta, double delta_rel) {
     for (int j = 0; j < n; j++) {
         double Dj = A[j * n + j];
         for (int k = 0; k < j; k++) Dj -= D[k] * L[tri(j, k)] * L[tri(j, k)];
@@ -96,11 +98,15 @@ void oracle_modified_ldl(int n, const double *A, double *L, double *D, double be
             L[tri(i, j)] = l;
         }
         double tb = theta / beta;
-        Dj = fmax(fabs(Dj), fmax(tb * tb, delta));
+        Dj = fmax(fabs(Dj), fmax(tb * tb, fmax(delta, delta_rel * fabs(A[j * n + j]))));
         for (int i = j + 1; i < n; i++) L[tri(i, j)] /= Dj;
         D[j] = Dj;
         L[tri(j, j)] = 1.0;
     }
+}
+
+void oracle_modified_ldl(int n, const double *A, double *L, double *D, double beta, double delta) {
+    modified_ldl_core(n, A, L, D, beta, delta, 0.0);
 }
 
 /* S <- (L D L')^-1 S, forward then backward substitution, ldl.cl:505-537 */
@@ -154,11 +160,11 @@ static void gram(int m, int N, const double *A, const double *d, double *M) {
 }
 
 /* factor (ldl.cl:314-378): beta from the diagonal (ldl.cl:280-294), then modified LDL' */
-static void factor(int m, const double *M, double *L, double *D, double floor_) {
+static void factor(int m, const double *M, double *L, double *D, double floor_, double floor_rel) {
     double beta = 0.0;
     for (int j = 0; j < m; j++) beta = fmax(beta, fabs(M[j * m + j]));
     beta = sqrt(beta);
-    oracle_modified_ldl(m, M, L, D, beta, floor_);
+    modified_ldl_core(m, M, L, D, beta, floor_, floor_rel);
 }
 
 /*
@@ -186,7 +192,7 @@ static int newton_dy(int m, int N, const double *A, const double *x, const doubl
         t[k] = c[k] - aty + mu / x[k];
     }
     gram(m, N, A, d, wk->M);
-    factor(m, wk->M, wk->L, wk->D, o->pivot_floor);
+    factor(m, wk->M, wk->L, wk->D, o->pivot_floor, 0.0);
     for (int i = 0; i < m; i++) {
         double rho = b[i], adt = 0.0;
         for (int k = 0; k < N; k++) {
@@ -375,7 +381,8 @@ static int ipm_one_path(int m, int N, const double *A, const double *b, const do
  * tau-scaled residuals as ipm_one_path (hsd.c:156 stops on mu < 1e-12); infeasibility is declared from the
  * certificate itself -- status 4 when c'x > 0 and |b| tau + |rho| <= 100 eps c'x (x is then a primal ray),
  * status 2 when b'y < 0 and |c| tau + |sigma| <= 100 eps (-b'y) -- instead of from the signs of the objectives
- * once mu < 1e-12 (hsd.c:156-177); when both hold the larger certificate wins.  On exit with status 0 (and 5) x, y, z
+ * once mu < 1e-12 (hsd.c:156-177); when both hold the larger certificate wins; the LDL' pivot floor is relative to the
+ * pivot's own original diagonal entry (see the factor() call below).  On exit with status 0 (and 5) x, y, z
  * are divided by tau (hsd.c:266-273); with status 2/4 they are the certificate as it stands.
  */
 static int hsd_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
@@ -432,12 +439,11 @@ static int hsd_one_raw(int m, int N, const double *A, const double *b, const dou
             r1[k] = dmu / x[k] - z[k] + eta * wk->sigma[k];
         }
         gram(m, N, A, d, wk->M);
-        /* the pivot floor (primal_normal.cl:275, 1e-6 absolute) is too coarse here: a dual ray drives z up and the
-         * whole of M = A (x/z) A' down, and nearly-feasible infeasible LPs need pivots of 1e-7 |M| resolved.  This path
-         * uses pivot_floor^2, relative to max|diag M| once that falls below 1. */
-        double mdiag = 0.0;
-        for (int j = 0; j < m; j++) mdiag = fmax(mdiag, fabs(wk->M[j * m + j]));
-        factor(m, wk->M, wk->L, wk->D, o->pivot_floor * o->pivot_floor * fmin(1.0, mdiag));
+        /* The pivot floor (primal_normal.cl:275, 1e-6 absolute) does not fit this path: a dual ray drives z up and the
+         * whole of M = A (x/z) A' down, and nearly-feasible infeasible LPs need pivots of 1e-7 max|M| resolved -- while a
+         * rank-deficient A (duplicated rows) needs its numerically-zero pivots caught.  Both are served by a floor
+         * RELATIVE TO EACH PIVOT'S OWN ORIGINAL DIAGONAL ENTRY: D_j >= pivot_floor^2 |M_jj|  (1e-12 |M_jj|). */
+        factor(m, wk->M, wk->L, wk->D, 0.0, o->pivot_floor * o->pivot_floor);
         for (int i = 0; i < m; i++) {
             double s1 = 0.0, s2 = 0.0;
             for (int k = 0; k < N; k++) {

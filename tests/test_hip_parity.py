@@ -379,6 +379,26 @@ def test_hsd_slowly_collapsing_infeasible_lps_at_the_baseline_shape():
     check_certificates(elp.A.todense(), elp.b, elp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
 
 
+@pytest.mark.parametrize("solver_name", ["hip_dense_primal_normal", "hip_sparse_primal_normal"])
+@pytest.mark.parametrize("hsd", [False, True])
+def test_rank_deficient_constraints(solver_name, hsd):
+    """Duplicated constraint rows (with duplicated right-hand sides): the pivot floors -- absolute 1e-6 on the plain
+    path, 1e-12 of each pivot's own diagonal on the HSD path -- must catch the numerically-zero pivots.  Checked against
+    the oracle and, as absolute truth, against HiGHS (the reference's hsd.c is off by up to 40 % on these LPs)."""
+    from scipy.optimize import linprog
+    rs = np.random.RandomState(3)
+    A = rs.rand(6, 14); A = np.vstack([A, A[:3]])
+    b = 0.5 + rs.rand(40, 6); b = np.hstack([b, b[:, :3]]); c = 0.5 + rs.rand(40, 14)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry[solver_name](hsd=hsd)
+    lp.init(s); lp.solve(s)
+    r = oracle_on(lp, flags=32 if hsd else 0)
+    assert (s.status == 0).all() and (r["status"] == 0).all() and s.iters.max() < 40
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-8
+    truth = np.array([-linprog(-c[i], A_ub=A, b_ub=b[i], bounds=(0, None), method="highs").fun for i in range(8)])
+    assert rel_err(s.primal_obj[:8], truth).max() < 1e-8
+
+
 @pytest.mark.parametrize("m,n", [(16, 32), (32, 64)])
 @pytest.mark.parametrize("flags", [0, 16, 4, 8])
 def test_hsd_objective_parity_on_baseline_configs(m, n, flags):
