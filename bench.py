@@ -93,6 +93,10 @@ def main():
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
     ap.add_argument("--sync-gather", action="store_true", help="block on the result gather after every solve (no overlap)")
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="compute units the solve kernel leaves idle (opts.reserve_cus).  Default: 8 (one per XCD) when "
+                         "results are gathered across ranks -- the persistent solve kernel otherwise fills every CU and the "
+                         "RCCL copy kernels of the overlapped gather would have to wait for it to end -- else 0")
     ap.add_argument("--force-collectives", action="store_true",
                     help="development aid: take the multi-rank code path (process group, result gather, barriers) even "
                          "with one rank -- exercises the RCCL calls on a one-GPU box")
@@ -128,6 +132,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if args.rehearse else dev     # where collectives run
     multi = world > 1 or args.force_collectives
+    reserve = args.reserve_cus if args.reserve_cus is not None else (8 if multi else 0)
     if multi:
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -154,7 +159,7 @@ def main():
         from pycllp_amd.lp import StandardLP
         lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
         # hsd=True: the homogeneous self-dual variant needs 41 instead of 52 iterations on this workload
-        solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=True)
+        solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=True, reserve_cus=reserve)
         cpu = None
     else:
         m_, n_ = M, N_STD
@@ -162,7 +167,7 @@ def main():
         Ae, be, ce = problems.equality_arrays(A, b, c)
         Nn = Ae.shape[1]
         lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
-        solver = solver_registry["hip_dense_primal_normal"](device=dev)
+        solver = solver_registry["hip_dense_primal_normal"](device=dev, reserve_cus=reserve)
     lp.init(solver)
     bd = torch.as_tensor(be, device=dev)
     cd = torch.as_tensor(ce, device=dev)
@@ -304,7 +309,7 @@ def main():
                                     "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
                                     % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
                        "lps_per_gpu": B, "lps_total": B * world, "m": m_, "n": n_, "N_equality": Nn,
-                       "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world,
+                       "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world, "reserve_cus": reserve,
                        "kernel": "ipm_block_kernel (one LP per 256-thread workgroup), PYCLLP_FLAG_HSD" if sparse else
                                  "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
                                  % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},

@@ -82,7 +82,10 @@ typedef struct pycllp_hip_opts {
     int max_iter;       /* default 200 (primal_normal.cl:9)                                  */
     int max_refine;     /* default 5 (ldl.cl:645)                                            */
     int flags;          /* PYCLLP_FLAG_*                                                     */
-    int reserved;
+    int reserve_cus;    /* compute units the solve leaves idle (default 0).  The solve kernels are persistent and fill every CU
+                           completely (LDS and registers), so a kernel on another stream -- e.g. the RCCL copy kernels of the
+                           result gather that overlaps the next solve -- finds no free CU until a solve ends; reserving a few
+                           (8 = one per XCD) lets it run beside the solve                                    */
 } pycllp_hip_opts;
 
 typedef struct pycllp_hip_dense pycllp_hip_dense; /* opaque per-solver device state */

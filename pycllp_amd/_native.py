@@ -30,7 +30,7 @@ class Opts(ctypes.Structure):
     _fields_ = [("eps", ctypes.c_double), ("delta", ctypes.c_double), ("r", ctypes.c_double),
                 ("pivot_floor", ctypes.c_double), ("refine_tol", ctypes.c_double),
                 ("max_iter", ctypes.c_int), ("max_refine", ctypes.c_int), ("flags", ctypes.c_int),
-                ("reserved", ctypes.c_int)]
+                ("reserve_cus", ctypes.c_int)]
 
 
 _lib = None
@@ -84,7 +84,7 @@ def default_opts(**kw):
     o = Opts()
     lib().pycllp_hip_default_opts(ctypes.byref(o))
     for k, v in kw.items():
-        if k not in dict(Opts._fields_) or k == "reserved":
+        if k not in dict(Opts._fields_):
             raise TypeError("unknown solver option %r" % k)
         setattr(o, k, v)
     return o

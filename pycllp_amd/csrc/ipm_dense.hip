@@ -87,6 +87,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 struct DevOpts {
     double eps, delta, r, pivot_floor, refine_tol;
     int max_iter, max_refine, flags;
+    int reserve_cus;           // host side only: CUs left idle by the launch plan
     unsigned long long* prof;  // diagnostic build only (-DPYCLLP_PROFILE): per-wave phase cycle sums
 };
 
@@ -713,7 +714,7 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     long blocks = (B + per_block - 1) / per_block;
     // one persistent workgroup per CU: its 8 waves (4 for the HSD kernel, compiled for 512 registers) already use the
     // whole register file, so a second workgroup could not become resident whatever the LDS says
-    const long resident = (long)h->num_cu;
+    const long resident = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
@@ -783,6 +784,7 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
     DevOpts o;
     o.eps = d.eps; o.delta = d.delta; o.r = d.r; o.pivot_floor = d.pivot_floor; o.refine_tol = d.refine_tol;
     o.max_iter = d.max_iter; o.max_refine = d.max_refine; o.flags = d.flags;
+    o.reserve_cus = d.reserve_cus < 0 ? 0 : d.reserve_cus;
     o.prof = g_prof;
     return o;
 }
@@ -821,7 +823,7 @@ void pycllp_hip_default_opts(pycllp_hip_opts* o) {
     o->max_iter = 200;
     o->max_refine = 5;
     o->flags = 0;
-    o->reserved = 0;
+    o->reserve_cus = 0;
 }
 
 int pycllp_hip_dense_max_rows(void) { return 32; }
@@ -1067,7 +1069,8 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
     HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
-    long blocks = (long)h->num_cu * per_cu;
+    const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
+    long blocks = free_cus * per_cu;
     if (blocks > B) blocks = B;
     h->grid = (int)blocks;
     hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
