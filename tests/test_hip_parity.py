@@ -240,6 +240,16 @@ def test_concurrent_solves_on_two_streams_share_one_handle():
         assert int((buf["status"] != 0).sum()) == 0
 
 
+def test_reserve_cus_leaves_compute_units_idle_and_changes_nothing_else():
+    A, b, c = problems.random_dense_arrays(32, 64, 8192, seed=2)
+    elp, s0 = solve_arrays(A, b, c)
+    g0 = s0.launch_info()["grid"]
+    elp2, s8 = solve_arrays(A, b, c, reserve_cus=8)
+    assert s8.launch_info()["grid"] == g0 - 8
+    np.testing.assert_array_equal(s8.primal_obj, s0.primal_obj)
+    np.testing.assert_array_equal(s8.iters, s0.iters)
+
+
 def test_empty_batch():
     A = np.random.RandomState(0).rand(4, 6)
     lp = StandardLP(SparseMatrix(matrix=A), np.zeros((0, 4)), np.zeros((0, 6)), np.zeros(0)).to_equality_form()
