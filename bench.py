@@ -177,12 +177,13 @@ def main():
     # Result gather to rank 0 (the path's one collective).  It is issued asynchronously and overlaps the NEXT step's
     # solve: outputs are double-buffered (slot k%2), receive buffers on rank 0 too, and a slot is reused only after the
     # gather that read it has completed.  --sync-gather falls back to a blocking gather after every solve.
+    # The six result arrays of a solve are views into one packed allocation (HipDensePrimalNormalSolver._buffers), so the
+    # gather is ONE collective of gather_bytes per rank per step.
+    layout = solver._pack_layout(B)
+    gbytes = layout["_gather_bytes"]
     recv = None
     if multi and rank == 0:
-        shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "x": (B, Nn), "y": (B, m_)}
-        dts = {"status": torch.int32, "iters": torch.int32}
-        recv = [{f: [torch.empty(shapes[f], dtype=dts.get(f, torch.float64), device=cdev) for _ in range(world)]
-                 for f in fields} for _ in range(2)]
+        recv = [[torch.empty(gbytes, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
     pending = [None, None]
 
     def wait_slot(sl):
@@ -200,10 +201,9 @@ def main():
         if e1 is not None:
             e1.record()
         if multi:
-            works = []
-            for f in fields:
-                t = buf[f].to(cdev) if args.rehearse else buf[f]
-                works.append(dist.gather(t, recv[sl][f] if rank == 0 else None, dst=0, async_op=True))
+            t = buf["packed"][:gbytes]
+            t = t.to(cdev) if args.rehearse else t
+            works = [dist.gather(t, recv[sl] if rank == 0 else None, dst=0, async_op=True)]
             if args.sync_gather:
                 for wk in works:
                     wk.wait()
@@ -236,7 +236,8 @@ def main():
     gathered = None
     if multi and rank == 0:
         last = (args.steps - 1) % 2
-        gathered = {f: torch.cat(recv[last][f], dim=0) for f in fields}
+        parts = [solver.unpack(r, layout, names=fields) for r in recv[last]]
+        gathered = {f: torch.cat([pt[f] for pt in parts], dim=0) for f in fields}
 
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
     status = buf["status"].cpu().numpy()

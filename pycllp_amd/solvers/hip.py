@@ -96,19 +96,46 @@ class HipDensePrimalNormalSolver(BaseSolver):
         self.m, self.n = m, n
         self.buffers = {}
 
+    # order of the result arrays inside the one allocation that holds them (see _buffers)
+    _PACK_ORDER = (("pobj", torch.float64), ("dobj", torch.float64), ("status", torch.int32), ("iters", torch.int32),
+                   ("y", torch.float64), ("x", torch.float64), ("z", torch.float64))
+
+    def _pack_layout(self, B):
+        """(offset, nbytes, dtype, shape) of every result array in the packed allocation, 256-byte aligned sections;
+        everything up to and including x -- what a result gather ships -- forms a contiguous prefix."""
+        shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "y": (B, self.m), "x": (B, self.n),
+                  "z": (B, self.n)}
+        layout, off = {}, 0
+        for name, dt in self._PACK_ORDER:
+            nb = int(np.prod(shapes[name], dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+            layout[name] = (off, nb, dt, shapes[name])
+            off = (off + nb + 255) & ~255
+            if name == "x":
+                layout["_gather_bytes"] = off
+        layout["_total_bytes"] = off
+        return layout
+
+    @staticmethod
+    def unpack(packed, layout, names=("pobj", "dobj", "status", "iters", "y", "x")):
+        """Views of the result arrays inside a packed byte buffer (e.g. one received from another rank)."""
+        out = {}
+        for name in names:
+            off, nb, dt, shape = layout[name]
+            out[name] = packed[off:off + nb].view(dt).view(shape)
+        return out
+
     def _buffers(self, B, slot=0):
-        """Output tensors of one solve.  ``slot`` selects one of several independent sets so that a caller can keep
-        the results of solve k alive (e.g. while they are being gathered) during solve k+1."""
+        """Output tensors of one solve: views into ONE device allocation (``packed``, bytes), so that a caller who ships
+        the results elsewhere -- the multi-GPU gather -- moves a single contiguous buffer (its first ``gather_bytes``
+        bytes hold pobj, dobj, status, iters, y, x) instead of six.  ``slot`` selects one of several independent sets so
+        that the results of solve k stay alive (e.g. while they are being gathered) during solve k+1."""
         key = "set%d" % slot
         cur = self.buffers.get(key)
         if cur is None or cur["B"] != B:
-            dev, f64, i32 = self.device, torch.float64, torch.int32
-            cur = dict(
-                B=B,
-                x=torch.empty((B, self.n), dtype=f64, device=dev), z=torch.empty((B, self.n), dtype=f64, device=dev),
-                y=torch.empty((B, self.m), dtype=f64, device=dev),
-                pobj=torch.empty(B, dtype=f64, device=dev), dobj=torch.empty(B, dtype=f64, device=dev),
-                status=torch.empty(B, dtype=i32, device=dev), iters=torch.empty(B, dtype=i32, device=dev))
+            layout = self._pack_layout(B)
+            packed = torch.empty(max(layout["_total_bytes"], 256), dtype=torch.uint8, device=self.device)
+            cur = dict(B=B, packed=packed, layout=layout, gather_bytes=layout["_gather_bytes"])
+            cur.update(self.unpack(packed, layout, names=[n for n, _ in self._PACK_ORDER]))
             self.buffers[key] = cur
         return cur
 
