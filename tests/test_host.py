@@ -105,3 +105,27 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
                 assert "liboracle" not in text and "libhsd_ref" not in text, f
+
+
+def test_packed_result_layout_round_trip():
+    """The result arrays of a solve are views into one packed byte buffer (what the multi-GPU gather ships): the layout
+    must be aligned, non-overlapping, have the gathered arrays as a contiguous prefix, and unpack() must invert it."""
+    import torch
+    from pycllp_amd.solvers.hip import HipDensePrimalNormalSolver
+    s = HipDensePrimalNormalSolver()
+    s.m, s.n = 5, 13
+    for B in (0, 1, 7, 1000):
+        lay = s._pack_layout(B)
+        spans = sorted((off, off + nb, name) for name, (off, nb, dt, shape) in
+                       ((k, v) for k, v in lay.items() if not k.startswith("_")))
+        for (a0, a1, _), (b0, b1, _) in zip(spans[:-1], spans[1:]):
+            assert a1 <= b0
+        assert all(off % 256 == 0 for off, _, _ in spans)
+        assert lay["x"][0] + lay["x"][1] <= lay["_gather_bytes"] <= lay["z"][0] <= lay["_total_bytes"]
+        packed = torch.zeros(max(lay["_total_bytes"], 256), dtype=torch.uint8)
+        views = s.unpack(packed, lay, names=("pobj", "dobj", "status", "iters", "y", "x", "z"))
+        assert views["x"].shape == (B, 13) and views["y"].shape == (B, 5) and views["status"].dtype == torch.int32
+        if B:
+            views["x"][:] = 1.5; views["status"][:] = 7; views["z"][:] = -2.0
+            again = s.unpack(packed[:lay["_gather_bytes"]].clone(), lay)      # what a peer would receive
+            assert float(again["x"].sum()) == 1.5 * B * 13 and int(again["status"].sum()) == 7 * B
