@@ -68,6 +68,9 @@ extern "C" {
                                         identity (diagnostic: results must agree to rounding)                    */
 #define PYCLLP_FLAG_FORCE_GUARD_PATH 4 /* diagnostic: always run the guarded (cold) LDL' path of the group
                                           kernel; results must not change when the guard is inactive */
+#define PYCLLP_FLAG_BLOCK_KERNEL 64 /* sparse solver: use the workgroup-per-LP kernel (ipm_block_kernel) even where the
+                                       register-resident wavefront-per-LP kernel covers the problem (diagnostic / A-B runs;
+                                       results agree to rounding)                                                  */
 #define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead
                                      of the default one (one LP per 16/32-lane group)          */
 
@@ -132,6 +135,17 @@ void pycllp_hip_dense_free(pycllp_hip_dense *handle);
 int pycllp_hip_ldl(int n, long B, const double *A_dev, double *L_dev, double *D_dev, int modified, double beta,
                    double delta, void *stream);
 
+/* Stand-alone LDL' solves of B explicit symmetric systems (numpy prototypes pycllp/ldl.py:147-281).
+ * pycllp_hip_ldl_solve: x = A^-1 rhs through A = L D L' -- `solve_ldl` (ldl.py:202-239) when modified == 0 (one matrix
+ *   per wavefront, factor held in registers), `forward_backward_modified_ldl` (ldl.py:242-281: Nocedal-Wright guard with
+ *   the given beta and delta) when modified != 0.  A_dev [B, n, n] (lower triangle read), rhs_dev, x_dev [B, n]; n <= 128.
+ * pycllp_hip_forward_backward_ldl: x = (L D L')^-1 b for given factors -- `forward_backward_ldl` (ldl.py:165-180).
+ *   L_dev [B, n(n+1)/2] packed lower triangle as written by pycllp_hip_ldl (unit diagonal), D_dev, b_dev, x_dev [B, n]. */
+int pycllp_hip_ldl_solve(int n, long B, const double *A_dev, const double *rhs_dev, double *x_dev, int modified,
+                         double beta, double delta, void *stream);
+int pycllp_hip_forward_backward_ldl(int n, long B, const double *L_dev, const double *D_dev, const double *b_dev,
+                                    double *x_dev, void *stream);
+
 /* ---- sparse shared-A path (BASELINE config 5): one LP per workgroup, A in CSR, dense packed factor in LDS ----
  * Replaces ClSparsePrimalNormalSolver (pycllp/solvers/cl.py:127-278) and the sparse_* kernels
  * (pycllp/cl/primal_normal.cl:287-375, pycllp/cl/ldl.cl:140-196,221-257,381-502,540-574,656-712).
@@ -146,6 +160,15 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double *Adata_dev, const
 int pycllp_hip_sparse_solve(pycllp_hip_sparse *handle, long B, const double *b_dev, const double *c_dev,
                             double *x_dev, double *y_dev, double *z_dev, double *pobj_dev, double *dobj_dev,
                             int *status_dev, int *iters_dev, const pycllp_hip_opts *opts, void *stream);
+/* One Newton step of the primal normal equations for B independent states with the sparse shared A: the reference's
+ * stand-alone kernel sparse_solve_primal_normal (pycllp/cl/ldl.cl:656-712) as launched by its tests/test_ldl.py:276-361.
+ * Arguments as pycllp_hip_dense_newton. */
+int pycllp_hip_sparse_newton(pycllp_hip_sparse *handle, long B, const double *x_dev, const double *z_dev,
+                             const double *y_dev, const double *b_dev, const double *c_dev, double mu, double *dy_dev,
+                             int *nrefine_dev, const pycllp_hip_opts *opts, void *stream);
+/* grid (workgroups), LDS bytes per workgroup and kernel (0 = workgroup-per-LP block kernel, 1 = register-resident
+ * wavefront-per-LP kernel) of the last solve launch on this handle (host values; not thread-safe). */
+int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse *handle, int *grid, int *block, int *lds_bytes, int *kernel);
 void pycllp_hip_sparse_free(pycllp_hip_sparse *handle);
 
 #ifdef __cplusplus

@@ -17,12 +17,14 @@ EXPORTS = (
     "pycllp_hip_dense_solve", "pycllp_hip_dense_newton", "pycllp_hip_dense_launch_info",
     "pycllp_hip_dense_free", "pycllp_hip_ldl",
     "pycllp_hip_sparse_max_rows", "pycllp_hip_sparse_max_cols", "pycllp_hip_sparse_init", "pycllp_hip_sparse_solve",
-    "pycllp_hip_sparse_free",
+    "pycllp_hip_sparse_free", "pycllp_hip_sparse_newton", "pycllp_hip_sparse_launch_info",
+    "pycllp_hip_ldl_solve", "pycllp_hip_forward_backward_ldl",
 )
 
 STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
 FLAG_WARM_START, FLAG_WAVE_KERNEL, FLAG_FORCE_GUARD_PATH, FLAG_AUTOSCALE, FLAG_NO_SLACK_PATH = 1, 2, 4, 8, 16
 FLAG_HSD = 32
+FLAG_BLOCK_KERNEL = 64
 
 
 class Opts(ctypes.Structure):
@@ -70,6 +72,15 @@ def lib():
     L.pycllp_hip_sparse_init.restype = ctypes.c_int
     L.pycllp_hip_sparse_solve.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, dp, dp, ip, ip, ctypes.POINTER(Opts), vp]
     L.pycllp_hip_sparse_solve.restype = ctypes.c_int
+    L.pycllp_hip_sparse_newton.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, ctypes.c_double, dp, ip,
+                                           ctypes.POINTER(Opts), vp]
+    L.pycllp_hip_sparse_newton.restype = ctypes.c_int
+    L.pycllp_hip_sparse_launch_info.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int)] * 4
+    L.pycllp_hip_sparse_launch_info.restype = ctypes.c_int
+    L.pycllp_hip_ldl_solve.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
+    L.pycllp_hip_ldl_solve.restype = ctypes.c_int
+    L.pycllp_hip_forward_backward_ldl.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, dp, vp]
+    L.pycllp_hip_forward_backward_ldl.restype = ctypes.c_int
     L.pycllp_hip_sparse_free.argtypes = [vp]
     L.pycllp_hip_sparse_free.restype = None
     L.pycllp_hip_dense_free.argtypes = [vp]

@@ -23,99 +23,7 @@
 // Numerical semantics follow oracle/ipm_dense_ref.c (the CPU restatement used by the tests), i.e. the
 // reference algorithm with the SURVEY section 8(a) picks: relative stopping tolerance, DELTA/R of the
 // OpenCL kernel, Nocedal-Wright diagonal guard, |r|-driven iterative refinement, NaN guard.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdio.h>
-#include <string.h>
-
-#include <algorithm>
-#include <atomic>
-#include <type_traits>
-#include <vector>
-
-#include "../../include/pycllp_hip.h"
-
-// The 10x-growth exits (primal_normal.cl:261-269) keep the reference's own floor -- EPS = 1e-7f absolute, which is
-// 1e3 x the relative stopping tolerance used here (for |b|, |c| ~ 1) -- instead of the stopping tolerance itself:
-// within a factor 1000 of convergence a residual is rounding noise, and a 10x bump of noise is not divergence.
-#define PYCLLP_GROWTH_FLOOR 1e3
-
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-#define WAVE 64
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_d(double v, int srclane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, srclane);
-    hi = __builtin_amdgcn_readlane(hi, srclane);
-    return __hiloint2double(hi, lo);
-}
-
-// 1/a for a normal, positive a: v_rcp_f64 seed + two Newton steps (<= 1 ulp); skips the scaling/fix-up of an
-// IEEE division, which the LDL' pivots (floored at pivot_floor) never need
-__device__ __forceinline__ double fast_rcp(double a) {
-    double r = __builtin_amdgcn_rcp(a);
-    r = fma(r, fma(-a, r, 1.0), r);
-    r = fma(r, fma(-a, r, 1.0), r);
-    return r;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-    asm volatile("" : "+v"(v));   // no fma contraction of the first stage with v's producer: see grp_sum
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
-
-// Wave-private LDS hand-off: DS operations of one wave execute in order, so only the compiler has
-// to be kept from moving a read above the write it depends on.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct DevOpts {
-    double eps, delta, r, pivot_floor, refine_tol;
-    int max_iter, max_refine, flags;
-    int reserve_cus;           // host side only: CUs left idle by the launch plan
-    unsigned long long* prof;  // diagnostic build only (-DPYCLLP_PROFILE): per-wave phase cycle sums
-};
-
-// In-kernel phase stamps (diagnostic build only; the shipped library has no stamp executing).
-#ifdef PYCLLP_PROFILE
-#define NPHASE 10
-#ifdef PYCLLP_PROFILE_LITE   // fewer live counters: the full set costs registers and distorts a kernel at the VGPR limit
-#define PHASE_MAP(i) ((i) <= 1 ? 0 : (i) == 2 ? 2 : (i) <= 4 ? 4 : (i) == 5 ? 5 : (i) <= 7 ? 6 : 8)
-#else
-#define PHASE_MAP(i) (i)
-#endif
-#define STAMP_DECL unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0}; \
-    { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define STAMP(i) { unsigned long long t_now_; __builtin_amdgcn_sched_barrier(0); \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now_) :: "memory"); __builtin_amdgcn_sched_barrier(0); \
-    t_acc_[PHASE_MAP(i)] += t_now_ - t_prev_; t_prev_ = t_now_; }
-#define STAMP_ARGS , unsigned long long& t_prev_, unsigned long long (&t_acc_)[NPHASE]
-#define STAMP_PASS , t_prev_, t_acc_
-#define STAMP_FLUSH(o, wid) if ((o).prof && lane == 0) { for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_]; }
-#define STAMP_FLUSH_BLOCK(o, wid) for (int i_ = 0; i_ < NPHASE; i_++) (o).prof[(size_t)(wid) * NPHASE + i_] = t_acc_[i_];
-#else
-#define STAMP_FLUSH_BLOCK(o, wid)
-#define STAMP_DECL
-#define STAMP(i)
-#define STAMP_ARGS
-#define STAMP_PASS
-#define STAMP_FLUSH(o, wid)
-#endif
+#include "wreg.h"
 
 // ------------------------------------------------------------------------------------------------
 // compile-time geometry
@@ -773,7 +681,7 @@ static const SlackVariant kSlackVariants[] = {
 static const int kNumSlackVariants = sizeof(kSlackVariants) / sizeof(kSlackVariants[0]);
 
 static unsigned long long* g_prof = nullptr;  // diagnostic build only
-#ifdef PYCLLP_PROFILE
+#if defined(PYCLLP_PROFILE) || defined(PYCLLP_WREG_DEBUG)
 extern "C" void pycllp_hip_debug_set_prof(void* p) { g_prof = (unsigned long long*)p; }
 #endif
 
@@ -796,6 +704,8 @@ struct pycllp_hip_sparse {
     int* queue;         // ring of kQueueRing work-queue heads (see pycllp_hip_dense)
     std::atomic<unsigned> qnext;
     int lds, num_cu, grid;
+    int last_wreg;      // 1 when the last solve ran on the wave kernel
+    WregPlan* wreg;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
 };
 
 template <typename T>
@@ -1051,6 +961,16 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
         (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
         return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_init: problem does not fit in LDS");
     }
+    // the register-resident one-LP-per-wavefront kernel takes over whenever its tables fit (ipm_wreg.hip)
+    {
+        WregPlan* wp = nullptr;
+        const int rc = wreg_plan_create(m, n, nnz, val.data(), ptr.data(), col.data(), max_lds, st, &wp);
+        if (rc >= 1000) {
+            (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
+            return set_err(rc - 1000, "wreg_plan_create");
+        }
+        h->wreg = (rc == 0) ? wp : nullptr;
+    }
     *handle = h;
     return 0;
 }
@@ -1068,15 +988,105 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
     int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
     HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
+    int* worklist = nullptr;
+    const bool use_wreg = h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_HSD | PYCLLP_FLAG_AUTOSCALE));
+    h->last_wreg = use_wreg ? 1 : 0;
+    if (use_wreg) {
+        // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
+        HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));
+        hipError_t ew = wreg_launch_solve(h->wreg, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev,
+                                          iters_dev, qhead, worklist, o, h->num_cu, st, &h->grid);
+        if (ew != hipSuccess) { (void)hipFreeAsync(worklist, st); return set_err((int)ew, "ipm_wreg_kernel launch"); }
+        qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
+        HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
+    }
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     long blocks = free_cus * per_cu;
     if (blocks > B) blocks = B;
-    h->grid = (int)blocks;
+    if (!use_wreg) h->grid = (int)blocks;
     hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
-                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, o);
+                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, o);
     hipError_t e = hipGetLastError();
+    if (worklist) { hipError_t e2 = hipFreeAsync(worklist, st); if (e == hipSuccess) e = e2; }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
+    return 0;
+}
+
+int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, const double* z_dev, const double* y_dev,
+                             const double* b_dev, const double* c_dev, double mu, double* dy_dev, int* nrefine_dev,
+                             const pycllp_hip_opts* opts, void* stream) {
+    if (!h || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_newton: bad argument");
+    if (B == 0) return 0;
+    if (!x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev)
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_newton: bad argument");
+    if (!h->wreg) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_newton: the stand-alone step needs the register-resident kernel, "
+                 "which does not cover this matrix (m=%d, n=%d)", h->desc.m, h->desc.n);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    DevOpts o = to_dev(opts);
+    hipError_t e = wreg_launch_newton(h->wreg, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o, h->num_cu,
+                                      (hipStream_t)stream);
+    if (e != hipSuccess) return set_err((int)e, "newton_wreg_kernel launch");
+    return 0;
+}
+
+int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse* h, int* grid, int* block, int* lds_bytes, int* kernel) {
+    if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_launch_info: bad argument");
+    if (grid) *grid = h->grid;
+    if (block) *block = BLK_T;
+    if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->wreg) : h->lds;
+    if (kernel) *kernel = h->last_wreg;
+    return 0;
+}
+
+int pycllp_hip_ldl_solve(int n, long B, const double* A_dev, const double* rhs_dev, double* x_dev, int modified, double beta,
+                         double delta, void* stream) {
+    if (n <= 0 || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl_solve: bad argument");
+    if (B == 0) return 0;
+    if (!A_dev || !rhs_dev || !x_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl_solve: bad argument");
+    if (n > LDL_MAX_N) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_ldl_solve: n=%d exceeds the compiled kernel (n<=%d)", n, LDL_MAX_N);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    if (modified && !(beta > 0.0)) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl_solve: beta must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    if (!modified) {
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        hipError_t e = wreg_launch_ldl_solve(n, B, A_dev, rhs_dev, x_dev, 0.0, ncu, st);
+        if (e != hipSuccess) return set_err((int)e, "ldl_solve_wreg_kernel launch");
+        return 0;
+    }
+    const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) + n + 8));
+    hipError_t e = hipFuncSetAttribute((const void*)ldl_solve_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(ldl_solve_batched_kernel)");
+    const long blocks = B < 4096 ? B : 4096;
+    hipLaunchKernelGGL(ldl_solve_batched_kernel, dim3((unsigned)blocks), dim3(n <= 64 ? 64 : 128), lds, st, n, B, A_dev, rhs_dev,
+                       x_dev, modified, beta, delta);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_err((int)e, "ldl_solve_batched_kernel launch");
+    return 0;
+}
+
+int pycllp_hip_forward_backward_ldl(int n, long B, const double* L_dev, const double* D_dev, const double* b_dev, double* x_dev,
+                                    void* stream) {
+    if (n <= 0 || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_forward_backward_ldl: bad argument");
+    if (B == 0) return 0;
+    if (!L_dev || !D_dev || !b_dev || !x_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_forward_backward_ldl: bad argument");
+    if (n > LDL_MAX_N) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_forward_backward_ldl: n=%d exceeds the compiled kernel (n<=%d)", n, LDL_MAX_N);
+        return PYCLLP_E_UNSUPPORTED;
+    }
+    const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) / 2 + n + 8));
+    hipError_t e = hipFuncSetAttribute((const void*)forward_backward_ldl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(forward_backward_ldl_kernel)");
+    const long blocks = B < 4096 ? B : 4096;
+    hipLaunchKernelGGL(forward_backward_ldl_kernel, dim3((unsigned)blocks), dim3(n <= 64 ? 64 : 128), lds, (hipStream_t)stream, n, B,
+                       L_dev, D_dev, b_dev, x_dev);
+    e = hipGetLastError();
+    if (e != hipSuccess) return set_err((int)e, "forward_backward_ldl_kernel launch");
     return 0;
 }
 
@@ -1084,6 +1094,7 @@ void pycllp_hip_sparse_free(pycllp_hip_sparse* h) {
     if (!h) return;
     if (h->dev_blob) (void)hipFree(h->dev_blob);
     if (h->queue) (void)hipFree(h->queue);
+    wreg_plan_free(h->wreg);
     free(h);
 }
 
