@@ -13,13 +13,15 @@
 // each of the 4 SIMDs of a CU runs one wavefront with the full 512-register budget that owns one LP:
 //   * the factor is kept as U = L' in 16 x 16 blocks U[K][I] (K <= I) in the ACCUMULATOR layout of
 //     v_mfma_f64_16x16x4_f64 (register r of lane l holds element [4r + (l >> 4)][l & 15]): 36 blocks x 4 doubles at
-//     m = 128.  That layout is, unchanged, the B operand of the block and the A operand of its transpose, so both the
+//     m = 128 (see below: 28 of them resident).  That layout is, unchanged, the B operand of the block and the A operand of its transpose, so both the
 //     panel solve  Y_KI = L_KK^-1 M_KI  and the trailing update  U_JI -= Y_KJ' U_KI  are MFMAs straight on the resident
 //     registers -- no operand ever moves;
-//   * the 16 x 16 diagonal block goes through a 2 KB LDS tile into "lane = row" form, is factored there by a 16-step
-//     DPP (row_newbcast) chain -- every 16-lane row of the wave redundantly, so nothing is broadcast across rows --
-//     and its inverse W_K = L_KK^-1 is formed directly in the MFMA A-operand layout (quad q owns columns q, q+4, ...);
-//     W_K then takes the place of the dead diagonal block and also serves the triangular solves;
+//   * only the 28 OFF-DIAGONAL blocks live in registers (224 of the 256 accumulator registers).  A diagonal block is
+//     formed when its turn comes (left-looking): its Schur update on the matrix cores, plus the original block straight
+//     from the tables, into a 2 KB LDS tile; from there it is read in "lane = row" form and factored by a 16-step DPP
+//     (row_newbcast) chain -- every 16-lane row of the wave redundantly, so nothing is broadcast across rows -- and its
+//     inverse W_K = L_KK^-1 is formed directly in the MFMA A-operand layout (quad q owns columns q, q+4, ...) for the
+//     panel; W_K is also what the triangular solves use, from a packed copy in LDS (1 KB per block);
 //   * M = A diag(x/z) A' is assembled from entry/term tables built once at init (deterministic, atomic-free),
 //     scattered through a 8 KB LDS stage one block column at a time and loaded in the accumulator layout;
 //   * A x and A'u use ELL copies of A (by rows / by columns) in LDS; N-vectors live in registers (lane = column),
@@ -32,55 +34,67 @@
 // tools/wreg_sim.py is a lane-level numpy model of the layouts used below.
 #include "wreg.h"
 
-// bring-up aid (-DPYCLLP_WREG_DEBUG): progress marks into a host-visible buffer (DevOpts.prof, set through
-// pycllp_hip_debug_set_prof) so that a kernel that never ends can still be located
-#ifdef PYCLLP_WREG_DEBUG
-#define DBG_MARK(o, k, val) do { if ((o).prof && (threadIdx.x & 63) == 0) { \
-    volatile unsigned long long* p_ = (o).prof + (size_t)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32; \
-    p_[k] = (unsigned long long)(val); __threadfence_system(); } } while (0)
-#else
-#define DBG_MARK(o, k, val)
-#endif
-
 namespace {
 
-// An inline-asm operand of the accumulator register class: with one in the kernel the compiler selects the AGPR form of
-// the MFMAs (C/D -- the resident U blocks -- stay in a0..a255, A/B are read from either file); without it it takes the
-// VGPR form, where all 144 doubles of U would have to pass through the 256 architectural VGPRs around every MFMA.
+// An inline-asm operand of the accumulator register class: with one in the kernel the compiler keeps the AGPR form of
+// the MFMAs (C/D -- the resident U blocks -- in a0..a255, A/B read from either file).
 #define USE_AGPR_FORM() do { int agpr_hint_; asm volatile("; accumulator file in use" : "=a"(agpr_hint_)); } while (0)
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// A finished panel block, PARKED in eight accumulator registers.  The values are written there by inline asm with an
+// accumulator-class output, which is the one way to tell the register allocator where a long-lived, rarely read value
+// belongs: left to itself it keeps the panel results in architectural VGPRs (their next use is an MFMA B operand, which
+// may come from either file) and, out of VGPRs, spills them to scratch -- with one wavefront per SIMD every scratch
+// reload is a fully exposed memory round trip (first version of this kernel: 345 k cycles per iteration, 42 % of them in
+// the pivot chains waiting for reloads).  Reads are plain uses: the compiler copies them out (v_accvgpr_read) itself and
+// keeps track of the hazards.
+struct PBlk { int h[8]; };
+__device__ __forceinline__ void park(PBlk& p, const double4_t& v) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int lo = __double2loint(v[r]), hi = __double2hiint(v[r]);
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(p.h[2 * r]) : "v"(lo));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(p.h[2 * r + 1]) : "v"(hi));
+    }
+}
+__device__ __forceinline__ double unpark(const PBlk& p, int r) { return __hiloint2double(p.h[2 * r + 1], p.h[2 * r]); }
+
 constexpr int HB = 4;            // 16 x 16 blocks per Gram staging chunk (8 KB of LDS)
 constexpr int STAGE_D = HB * 256;
 constexpr int TILE_OFF = 512, RR_OFF = 800;   // aliases inside the stage (free once the blocks are in registers)
+constexpr int WL = 128;          // doubles reserved per packed W block (120 used: strictly lower triangle, row i at i(i-1)/2)
 constexpr int MAX_NQ = 8;
-constexpr int META_SEG = 2 * MAX_NQ, META_DSEG = META_SEG + 24, META_N = META_DSEG + 24;
+constexpr int META_SEG = MAX_NQ, META_DSEG = META_SEG + 24, META_N = META_DSEG + 24;
 
 template <int MB>
 struct WGeo {
     static constexpr int MP = 16 * MB;
     static constexpr int MR = (MP + 63) / 64;    // m-vector registers per lane in "lane = row" form
     static constexpr int MPL = 64 * MR;
-    static constexpr int NBLK = MB * (MB + 1) / 2;
-    __host__ __device__ static constexpr int bix(int K, int I) { return K * MB - K * (K - 1) / 2 + (I - K); }
-    // Gram staging chunks: block row K of U holds the off-diagonal blocks I = K+1 .. MB-1, staged HB at a time
+    static constexpr int NBLK = MB * (MB - 1) / 2;
+    // off-diagonal block (K, I), K < I, of U = L'
+    __host__ __device__ static constexpr int bix(int K, int I) { return K * MB - K * (K + 1) / 2 + (I - K - 1); }
+    // Gram staging chunks: block row K of U holds the blocks I = K+1 .. MB-1, staged HB at a time
     __host__ __device__ static constexpr int nch(int K) { return (MB - 1 - K + HB - 1) / HB; }
     __host__ __device__ static constexpr int chbase(int K) { int s = 0; for (int k = 0; k < K; k++) s += nch(k); return s; }
     static constexpr int NCHUNK = chbase(MB);
+    static constexpr int WAVE_D(int NQ) { return STAGE_D + 64 * NQ + 6 * MP + MB * WL; }   // per-wave LDS doubles
 };
 
 // Device view of the tables of one constraint matrix (built by wreg_plan_create).
 struct WregTab {
-    int m, n;
-    int rmax, ctot, n_ent, n_term;
-    int meta[META_N];                 // [0..8) ELL depth of column register q, [8..16) its first slot, [META_SEG..) first
-                                      // Gram entry of staging chunk i (chunks in (K, ch) order; NCHUNK + 1 used),
-                                      // [META_DSEG..) first Gram entry of diagonal block K (MB + 1 used) -- copied to LDS
-    const double* er_val; const unsigned short* er_col;   // A by rows, ELL [rmax][MPL]
-    const double* ec_val; const unsigned short* ec_row;   // A by columns, ELL [ctot][64]
-    const unsigned* e_ptr; const unsigned short* e_dst;   // Gram entries: term range, offset inside the stage
+    int m, n, nnz;
+    int rmax, n_ent, n_term;
+    int meta[META_N];     // [0..8) deepest column of column register q, [META_SEG..) first Gram entry of staging chunk i
+                          // (chunks in (K, ch) order; NCHUNK + 1 used), [META_DSEG..) first Gram entry of diagonal block
+                          // K (MB + 1 used) -- copied to LDS
+    const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
+    const double* csc_val; const unsigned short* csc_row; const unsigned short* csc_ptr; const unsigned short* csc_len;
+    const unsigned* e_ptr; const unsigned short* e_dst;   // Gram entries: term range, offset inside the stage / tile
     const double* t_w; const unsigned short* t_col;       // Gram terms: a_ij a_kj and the column j
-    int o_er_val, o_ec_val, o_t_w, o_wave, o_e_ptr, o_meta, o_er_col, o_ec_row, o_e_dst, o_t_col;   // LDS byte offsets
+    int o_csr_val, o_csc_val, o_t_w, o_wave, o_e_ptr, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_csc_row, o_csc_ptr,
+        o_csc_len, o_e_dst, o_t_col;                      // LDS byte offsets
     int wave_doubles, lds_bytes;
 };
 
@@ -128,62 +142,92 @@ struct WReg {
     using G = WGeo<MB>;
     static constexpr int MP = G::MP, MR = G::MR, MPL = G::MPL, NP = 64 * NQ;
 
-    double4_t U[G::NBLK];          // U[bix(K, I)], K <= I; after factor(): [K][K] holds W_K = L_KK^-1 (A-operand layout)
-    // LDS: shared tables
-    const double* er_val; const unsigned short* er_col;
-    const double* ec_val; const unsigned short* ec_row;
+    // Off-diagonal blocks [bix(K, I)], K < I.  Life of a block: gram() parks the original M_KI in P; the trailing update
+    // of stage_() 0 takes it out as an MFMA accumulator (U) where it stays through the following stages' updates; panel K
+    // turns it into Y_KI = D_K L_IK' and parks that in P for the rest of the Newton step.
+    double4_t U[G::NBLK > 0 ? G::NBLK : 1];
+    PBlk P[G::NBLK > 0 ? G::NBLK : 1];
+    // LDS: shared tables (A by rows and by columns in compact form, Gram entries/terms)
+    const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
+    const double* csc_val; const unsigned short* csc_row; const unsigned short* csc_ptr; const unsigned short* csc_len;
     const unsigned* e_ptr; const unsigned short* e_dst;
     const double* t_w; const unsigned short* t_col;
-    // LDS: this wave's area
-    double* stage;   // [STAGE_D] Gram staging; aliases: vx = stage[0..NP), tile, rr
-    double* vd;      // [NP] d = x/z
-    double* ys;      // [MP] y
-    double* bs;      // [MP] b
-    double* um;      // [MP] solve vector in/out
-    double* rdv;     // [MP] 1/D
-    double* flr;     // [MP] per-column pivot floors (HSD)
-    double* adv;     // [MP] D (the floored pivots)
-    const int* meta; // LDS: [0..8) ELL depth per column register, [8..16) first ELL slot, [16..) first Gram entry per chunk
+    const int* meta;
+    // LDS: this wave's area, every array at a COMPILE-TIME offset from the one base pointer W0 -- so that the address
+    // arithmetic of all of them folds into a handful of lane-dependent bases plus immediate offsets (as separate
+    // run-time pointers every (array, index pattern) pair costs a VGPR for the whole kernel)
+    double* W0;
+    __device__ __forceinline__ double* stage_() const { return W0; }                            // [STAGE_D] Gram staging; aliases: vx = stage_()[0..NP), tile, rr
+    __device__ __forceinline__ double* vd_() const { return W0 + STAGE_D; }                     // [NP] d = x/z
+    __device__ __forceinline__ double* ys_() const { return W0 + STAGE_D + NP; }                // [MP] y
+    __device__ __forceinline__ double* bs_() const { return W0 + STAGE_D + NP + MP; }           // [MP] b
+    __device__ __forceinline__ double* um_() const { return W0 + STAGE_D + NP + 2 * MP; }       // [MP] solve vector in/out
+    __device__ __forceinline__ double* rdv_() const { return W0 + STAGE_D + NP + 3 * MP; }      // [MP] 1/D
+    __device__ __forceinline__ double* flr_() const { return W0 + STAGE_D + NP + 4 * MP; }      // [MP] per-column pivot floors (HSD)
+    __device__ __forceinline__ double* adv_() const { return W0 + STAGE_D + NP + 5 * MP; }      // [MP] D (the floored pivots)
+    __device__ __forceinline__ double* wl_() const { return W0 + STAGE_D + NP + 6 * MP; }       // [MB][WL] W_K = L_KK^-1, strict lower triangle packed by rows
     int lane, q, c16, m, n, rmax;
 
+    // out_q = (A'u)_j for the columns j = lane + 64 q of this lane, u in LDS.  The NQ column registers advance together
+    // (t outer, q inner): NQ independent gather chains in flight instead of one.
     __device__ __forceinline__ void At(const double* u, double (&out)[NQ]) const {
+        int ptr[NQ], len[NQ];
+        int cm = 0;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            double acc = 0.0;
-            const int cm = __builtin_amdgcn_readfirstlane(meta[qq]);
-            const int base = __builtin_amdgcn_readfirstlane(meta[MAX_NQ + qq]) * 64 + lane;
-#pragma unroll 4
-            for (int t = 0; t < cm; t++) acc = fma(ec_val[base + 64 * t], u[ec_row[base + 64 * t]], acc);
-            out[qq] = acc;
+            ptr[qq] = csc_ptr[lane + 64 * qq]; len[qq] = csc_len[lane + 64 * qq];
+            out[qq] = 0.0;
+            cm = max(cm, __builtin_amdgcn_readfirstlane(meta[qq]));
         }
-    }
-    // (A v)_i for the rows i = lane + 64 r2 of this lane, v staged in LDS
-    __device__ __forceinline__ void Arow(const double* v, double (&out)[MR]) const {
+#pragma unroll 2
+        for (int t = 0; t < cm; t++) {
 #pragma unroll
-        for (int r2 = 0; r2 < MR; r2++) {
-            double acc = 0.0;
-            const int base = lane + 64 * r2;
-#pragma unroll 4
-            for (int t = 0; t < rmax; t++) acc = fma(er_val[base + MPL * t], v[er_col[base + MPL * t]], acc);
-            out[r2] = acc;
-        }
-    }
-    // diag(A diag(d) A')_i, d staged in vd; padded rows get 1 (identity rows of M)
-    __device__ __forceinline__ void Mdiag(double (&out)[MR]) const {
-#pragma unroll
-        for (int r2 = 0; r2 < MR; r2++) {
-            double acc = 0.0;
-            const int base = lane + 64 * r2;
-#pragma unroll 4
-            for (int t = 0; t < rmax; t++) {
-                const double a = er_val[base + MPL * t];
-                acc = fma(a * a, vd[er_col[base + MPL * t]], acc);
+            for (int qq = 0; qq < NQ; qq++) {
+                const bool on = t < len[qq];
+                const int p = on ? ptr[qq] + t : 0;
+                const double a = csc_val[p];
+                const double uv = u[csc_row[p]];
+                out[qq] = fma(on ? a : 0.0, uv, out[qq]);
             }
-            out[r2] = (base < m) ? acc : 1.0;
+        }
+    }
+    // (A v)_i for the rows i = lane + 64 r2 of this lane, v staged in LDS; with DIAG also diag(A diag(d) A')_i (d in vd_();
+    // padded rows get 1: identity rows of M) from the same pass over the row
+    template <bool DIAG>
+    __device__ __forceinline__ void Arow(const double* v, double (&out)[MR], double (&md)[MR]) const {
+        int ptr[MR], len[MR];
+#pragma unroll
+        for (int r2 = 0; r2 < MR; r2++) {
+            ptr[r2] = csr_ptr[lane + 64 * r2]; len[r2] = csr_len[lane + 64 * r2];
+            out[r2] = 0.0; md[r2] = 0.0;
+        }
+#pragma unroll 4
+        for (int t = 0; t < rmax; t++) {
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const bool on = t < len[r2];
+                const int p = on ? ptr[r2] + t : 0;
+                const double a = on ? csr_val[p] : 0.0;
+                const int cidx = csr_col[p];
+                out[r2] = fma(a, v[cidx], out[r2]);
+                if (DIAG) md[r2] = fma(a * a, vd_()[cidx], md[r2]);
+            }
+        }
+        if (DIAG) {
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) md[r2] = (lane + 64 * r2 < m) ? md[r2] : 1.0;
         }
     }
 
-    // Off-diagonal blocks of M = A diag(d) A' (d in vd) -> U, one staging chunk of <= HB blocks at a time.  The diagonal
+    // value of Gram entry e: sum over its terms of a_ij a_kj d_j
+    __device__ __forceinline__ double entry_value(int e) const {
+        const unsigned p1 = e_ptr[e + 1];
+        double acc = 0.0;
+        for (unsigned p = e_ptr[e]; p < p1; p++) acc = fma(t_w[p], vd_()[t_col[p]], acc);
+        return acc;
+    }
+
+    // Off-diagonal blocks of M = A diag(d) A' (d in vd_()) -> U, one staging chunk of <= HB blocks at a time.  The diagonal
     // blocks are NOT kept in registers: factor() rebuilds block K from the tables when its turn comes (diag_from_tables).
     __device__ __forceinline__ void gram() {
         static_for<0, MB>([&](auto Kc) {
@@ -195,20 +239,23 @@ struct WReg {
                 constexpr int ci = G::chbase(K) + ch;
                 const double2_t zero = {0.0, 0.0};
 #pragma unroll
-                for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage)[w * 64 + lane] = zero;
+                for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage_())[w * 64 + lane] = zero;
                 wave_lds_sync();
                 const int e1 = __builtin_amdgcn_readfirstlane(meta[META_SEG + ci + 1]);
-                for (int e = __builtin_amdgcn_readfirstlane(meta[META_SEG + ci]) + lane; e < e1; e += 64) {
-                    const unsigned p1 = e_ptr[e + 1];
-                    double acc = 0.0;
-                    for (unsigned p = e_ptr[e]; p < p1; p++) acc = fma(t_w[p], vd[t_col[p]], acc);
-                    stage[e_dst[e]] = acc;
+                int e = __builtin_amdgcn_readfirstlane(meta[META_SEG + ci]) + lane;
+                for (; e + 64 < e1; e += 128) {          // two entries per lane per trip: two independent chains
+                    const double v0 = entry_value(e), v1 = entry_value(e + 64);
+                    stage_()[e_dst[e]] = v0; stage_()[e_dst[e + 64]] = v1;
                 }
+                if (e < e1) stage_()[e_dst[e]] = entry_value(e);
                 wave_lds_sync();
 #pragma unroll
-                for (int bi = 0; bi < nb; bi++)
+                for (int bi = 0; bi < nb; bi++) {
+                    double4_t blk;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) U[G::bix(K, I0 + bi)][r] = stage[bi * 256 + 64 * r + lane];
+                    for (int r = 0; r < 4; r++) blk[r] = stage_()[bi * 256 + 64 * r + lane];
+                    park(P[G::bix(K, I0 + bi)], blk);
+                }
                 wave_lds_sync();
             });
         });
@@ -218,23 +265,28 @@ struct WReg {
     template <int K>
     __device__ __forceinline__ void diag_from_tables(double* tile, const double (&Md)[MR]) const {
         const int e1 = __builtin_amdgcn_readfirstlane(meta[META_DSEG + K + 1]);
-        for (int e = __builtin_amdgcn_readfirstlane(meta[META_DSEG + K]) + lane; e < e1; e += 64) {
-            const unsigned p1 = e_ptr[e + 1];
-            double acc = 0.0;
-            for (unsigned p = e_ptr[e]; p < p1; p++) acc = fma(t_w[p], vd[t_col[p]], acc);
-            tile[e_dst[e]] += acc;
-        }
+        for (int e = __builtin_amdgcn_readfirstlane(meta[META_DSEG + K]) + lane; e < e1; e += 64) tile[e_dst[e]] += entry_value(e);
         if (q == (K & 3)) tile[c16 * 18] += Md[K >> 2];   // row 16K + c16 lives in lane 16(K&3) + c16 of register K>>2
+    }
+
+    // W_K element [row c16][column 4s + q] from the packed copy in LDS
+    template <int K>
+    __device__ __forceinline__ double w_elem(int s) const {
+        const int col = 4 * s + q;
+        const double v = wl_()[K * WL + ((col < c16) ? c16 * (c16 - 1) / 2 + col : 0)];
+        return (col < c16) ? v : ((col == c16) ? 1.0 : 0.0);
     }
 
     // Blocked LDL' of the matrix whose off-diagonal blocks are in U; `diag_add(Kc, tile)` adds the original diagonal
     // block K (element [i][k], k <= i, at tile[17 i + k]) to the tile that already holds its Schur update.
-    // RELF: pivot floor of column j is flr[j] (LDS) instead of floor_.
+    // RELF: pivot floor of column j is flr_()[j] (LDS) instead of floor_.
     // Returns (wave-uniform) whether the Nocedal-Wright guard would have bitten anywhere.
     template <bool RELF, typename DiagAdd>
-    __device__ __forceinline__ bool factor(double beta2, double floor_, DiagAdd&& diag_add) {
-        bool viol = false;
-        double* tile = stage + TILE_OFF;
+    __device__ __forceinline__ bool factor(double beta2, double floor_, DiagAdd&& diag_add STAMP_ARGS) {
+        // guard verdict, kept as a per-lane integer that every test is folded into AT ONCE (asm pin): left as a boolean the
+        // compiler sinks the 16 + 112 compares to the end of the sweep and keeps their operands alive until then
+        int viol = 0;
+        double* tile = stage_() + TILE_OFF;
         static_for<0, MB>([&](auto Kc) {
             constexpr int K = decltype(Kc)::value;
             // ---- diagonal block K, left-looking: Schur update -sum_{K'<K} (D U_K'K)' U_K'K on the matrix cores ----
@@ -243,20 +295,21 @@ struct WReg {
                 constexpr int K2 = decltype(Kp)::value;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const double u = U[G::bix(K2, K)][s];
-                    sch = __builtin_amdgcn_mfma_f64_16x16x4f64(-(u * adv[16 * K2 + 4 * s + q]), u, sch, 0, 0, 0);
+                    const double y = unpark(P[G::bix(K2, K)], s);
+                    sch = __builtin_amdgcn_mfma_f64_16x16x4f64(-(y * rdv_()[16 * K2 + 4 * s + q]), y, sch, 0, 0, 0);
                 }
             });
             // accumulator layout -> tile, + original block -> lane = row (each 16-lane row of the wave a redundant copy)
 #pragma unroll
             for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = sch[r];
             wave_lds_sync();
+            STAMP(2)
             diag_add(Kc, tile);
             wave_lds_sync();
             double Wd[16], Ld[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
-            const double myf = RELF ? flr[16 * K + c16] : floor_;
+            const double myf = RELF ? flr_()[16 * K + c16] : floor_;
             wave_lds_sync();
             double rDr[4] = {1.0, 1.0, 1.0, 1.0}, aDr[4] = {1.0, 1.0, 1.0, 1.0}, rdiag = 1.0, adiag = 1.0;
             static_for<0, 16>([&](auto jc) {
@@ -266,7 +319,7 @@ struct WReg {
                 const double aD = fmax(fabs(piv), RELF ? row_bcast<j>(myf) : floor_);
                 const double rD = fast_rcp(aD);
                 const bool below = c16 > j;
-                viol = viol | (below & (u * u > beta2 * aD));
+                viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
                 const double li = below ? u * rD : 0.0;
                 static_for<j + 1, 16>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
@@ -277,9 +330,13 @@ struct WReg {
                 aDr[j >> 2] = (q == (j & 3)) ? aD : aDr[j >> 2];
                 rdiag = (c16 == j) ? rD : rdiag;
                 adiag = (c16 == j) ? aD : adiag;
+                // select NOW: deferred to the end of the chain (where the scheduler sinks them) the 64 selects keep all
+                // 16 pivots and reciprocals alive and the chain spills
+                asm volatile("" : "+v"(rDr[j >> 2]), "+v"(aDr[j >> 2]), "+v"(rdiag), "+v"(adiag), "+v"(viol));
             });
-            if (q == 0) { rdv[16 * K + c16] = rdiag; adv[16 * K + c16] = adiag; }
-            // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q] ----
+            if (q == 0) { rdv_()[16 * K + c16] = rdiag; adv_()[16 * K + c16] = adiag; }
+            STAMP(3)
+            // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q]; packed copy to LDS ----
             double Ws[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
@@ -290,75 +347,84 @@ struct WReg {
                     if constexpr (4 * s <= j) Ws[s] = fma(-Ld[j], row_bcast<j>(Ws[s]), Ws[s]);
                 });
             });
-            // ---- panel: Y_KI = W M_KI on the matrix cores, U_KI = D^-1 Y_KI (guard test on the scaled block:
-            //      Y^2 > beta^2 D  <=>  U^2 D > beta^2) ----
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (4 * s + q < c16) wl_()[K * WL + c16 * (c16 - 1) / 2 + 4 * s + q] = Ws[s];
+            STAMP(4)
+            // ---- panel: Y_KI = W M_KI = D_K L_IK' on the matrix cores.  The block stays UNSCALED in its accumulator
+            //      registers (every use below is an MFMA operand or folds 1/D into a vector): nothing ever writes a
+            //      resident block from the VALU side.  Guard test: Y^2 > beta^2 D. ----
             static_for<K + 1, MB>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
                 double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[s], U[G::bix(K, I)][s], acc, 0, 0, 0);
+                for (int s = 0; s < 4; s++)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[s], (K == 0) ? unpark(P[G::bix(K, I)], s) : U[G::bix(K, I)][s], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double u = acc[r] * rDr[r];
-                    viol = viol | (u * u * aDr[r] > beta2);
-                    U[G::bix(K, I)][r] = u;
-                }
+                for (int r = 0; r < 4; r++) viol |= (acc[r] * acc[r] > beta2 * aDr[r]) ? 1 : 0;
+                asm volatile("" : "+v"(viol));
+                park(P[G::bix(K, I)], acc);
             });
-            // ---- trailing update of the off-diagonal blocks: U_JI -= (D U_KJ)' U_KI, J < I; the A operand -D U_KJ is
-            //      re-formed per block row J (keeping all of them alive would cost 8 registers per block) ----
+            STAMP(5)
+            // ---- trailing update of the off-diagonal blocks: M_JI -= Y_KJ' D_K^-1 Y_KI, J < I; the A operand
+            //      -D^-1 Y_KJ is formed per block row J ----
             static_for<K + 1, MB>([&](auto Jc) {
                 constexpr int J = decltype(Jc)::value;
                 double yn[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) yn[r] = -(U[G::bix(K, J)][r] * aDr[r]);
+                for (int r = 0; r < 4; r++) yn[r] = -(unpark(P[G::bix(K, J)], r) * rDr[r]);
                 static_for<J + 1, MB>([&](auto Ic) {
                     constexpr int I = decltype(Ic)::value;
-                    double4_t acc = U[G::bix(J, I)];
+                    double4_t acc;
+                    if constexpr (K == 0) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yn[s], U[G::bix(K, I)][s], acc, 0, 0, 0);
+                        for (int r = 0; r < 4; r++) acc[r] = unpark(P[G::bix(J, I)], r);
+                    } else {
+                        acc = U[G::bix(J, I)];
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yn[s], unpark(P[G::bix(K, I)], s), acc, 0, 0, 0);
                     U[G::bix(J, I)] = acc;
                 });
             });
-#pragma unroll
-            for (int s = 0; s < 4; s++) U[G::bix(K, K)][s] = Ws[s];
+            STAMP(6)
             __builtin_amdgcn_sched_barrier(0);   // one panel at a time: nothing of panel K+1 is hoisted above this line
         });
         wave_lds_sync();
-        return __any(viol);
+        return __any(viol != 0);
     }
 
-    // um <- (L D L')^-1 um.  Forward substitution is column oriented (t_K, once known, is folded into the partial sums of
+    // um_() <- (L D L')^-1 um_().  Forward substitution is column oriented (t_K, once known, is folded into the partial sums of
     // all later block rows and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
     __device__ __forceinline__ void solve() {
-        double* rr = stage + RR_OFF;
+        double* rr = stage_() + RR_OFF;
         double p[MB];
 #pragma unroll
         for (int I = 0; I < MB; I++) p[I] = 0.0;
         // forward: t_I = W_I (s_I - sum_{K<I} L_IK t_K)
         static_for<0, MB>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
-            double rC = um[16 * I + c16];
+            double rC = um_()[16 * I + c16];
             if constexpr (I > 0) rC -= quad_sum(p[I]);
             if (q == 0) rr[c16] = rC;
             wave_lds_sync();
             double pt = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) pt = fma(U[G::bix(I, I)][s], rr[4 * s + q], pt);
+            for (int s = 0; s < 4; s++) pt = fma(w_elem<I>(s), rr[4 * s + q], pt);
             const double tC = quad_sum(pt);
-            if (q == 0) um[16 * I + c16] = tC;
+            if (q == 0) um_()[16 * I + c16] = tC;
             wave_lds_sync();
             if constexpr (I + 1 < MB) {
-                double tR[4];
+                double tR[4];      // D_I^-1 t_I: the resident blocks are Y = D L'
 #pragma unroll
-                for (int r = 0; r < 4; r++) tR[r] = um[16 * I + 4 * r + q];
+                for (int r = 0; r < 4; r++) tR[r] = um_()[16 * I + 4 * r + q] * rdv_()[16 * I + 4 * r + q];
                 static_for<I + 1, MB>([&](auto Jc) {
                     constexpr int J = decltype(Jc)::value;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) p[J] = fma(U[G::bix(I, J)][r], tR[r], p[J]);
+                    for (int r = 0; r < 4; r++) p[J] = fma(unpark(P[G::bix(I, J)], r), tR[r], p[J]);
                 });
             }
         });
-        // backward: x_K = W_K' (D_K^-1 t_K - sum_{I>K} L_IK' x_I)
+        // backward: x_K = W_K' D_K^-1 (t_K - sum_{I>K} Y_KI x_I)
         double xCL[MB];
         static_for<0, MB>([&](auto Kr) {
             constexpr int K = MB - 1 - decltype(Kr)::value;
@@ -366,56 +432,68 @@ struct WReg {
             static_for<K + 1, MB>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
 #pragma unroll
-                for (int r = 0; r < 4; r++) pr[r] = fma(U[G::bix(K, I)][r], xCL[I], pr[r]);
+                for (int r = 0; r < 4; r++) pr[r] = fma(unpark(P[G::bix(K, I)], r), xCL[I], pr[r]);
             });
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                double v = um[16 * K + 4 * r + q] * rdv[16 * K + 4 * r + q];
+                double v = um_()[16 * K + 4 * r + q];
                 if constexpr (K < MB - 1) v -= row_sum(pr[r]);
+                v *= rdv_()[16 * K + 4 * r + q];
                 if (c16 == 0) rr[4 * r + q] = v;
             }
             wave_lds_sync();
             const double rC = rr[c16];
             double xs[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) xs[s] = row_sum(U[G::bix(K, K)][s] * rC);
+            for (int s = 0; s < 4; s++) xs[s] = row_sum(w_elem<K>(s) * rC);
             wave_lds_sync();
 #pragma unroll
-            for (int s = 0; s < 4; s++) if (c16 == 0) um[16 * K + 4 * s + q] = xs[s];
+            for (int s = 0; s < 4; s++) if (c16 == 0) um_()[16 * K + 4 * s + q] = xs[s];
             wave_lds_sync();
-            xCL[K] = um[16 * K + c16];
+            xCL[K] = um_()[16 * K + c16];
         });
         wave_lds_sync();
     }
 };
 
 template <int MB, int NQ>
+__device__ __forceinline__ void wreg_carve(WReg<MB, NQ>& w, double* W0, int tid) {
+    using G = WGeo<MB>;
+    w.W0 = W0;
+    w.lane = tid & 63; w.q = w.lane >> 4; w.c16 = w.lane & 15;
+}
+
+template <int MB, int NQ>
 __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, unsigned char* lraw, int tid) {
     using G = WGeo<MB>;
-    double* s_er_val = (double*)(lraw + T.o_er_val);
-    double* s_ec_val = (double*)(lraw + T.o_ec_val);
+    double* s_csr_val = (double*)(lraw + T.o_csr_val);
+    double* s_csc_val = (double*)(lraw + T.o_csc_val);
     double* s_t_w = (double*)(lraw + T.o_t_w);
     unsigned* s_e_ptr = (unsigned*)(lraw + T.o_e_ptr);
     int* s_meta = (int*)(lraw + T.o_meta);
-    unsigned short* s_er_col = (unsigned short*)(lraw + T.o_er_col);
-    unsigned short* s_ec_row = (unsigned short*)(lraw + T.o_ec_row);
+    unsigned short* s_csr_col = (unsigned short*)(lraw + T.o_csr_col);
+    unsigned short* s_csr_ptr = (unsigned short*)(lraw + T.o_csr_ptr);
+    unsigned short* s_csr_len = (unsigned short*)(lraw + T.o_csr_len);
+    unsigned short* s_csc_row = (unsigned short*)(lraw + T.o_csc_row);
+    unsigned short* s_csc_ptr = (unsigned short*)(lraw + T.o_csc_ptr);
+    unsigned short* s_csc_len = (unsigned short*)(lraw + T.o_csc_len);
     unsigned short* s_e_dst = (unsigned short*)(lraw + T.o_e_dst);
     unsigned short* s_t_col = (unsigned short*)(lraw + T.o_t_col);
     const int nth = blockDim.x;
-    for (int i = tid; i < T.rmax * G::MPL; i += nth) { s_er_val[i] = T.er_val[i]; s_er_col[i] = T.er_col[i]; }
-    for (int i = tid; i < T.ctot * 64; i += nth) { s_ec_val[i] = T.ec_val[i]; s_ec_row[i] = T.ec_row[i]; }
+    for (int i = tid; i < T.nnz; i += nth) {
+        s_csr_val[i] = T.csr_val[i]; s_csr_col[i] = T.csr_col[i]; s_csc_val[i] = T.csc_val[i]; s_csc_row[i] = T.csc_row[i];
+    }
+    for (int i = tid; i < G::MPL; i += nth) { s_csr_ptr[i] = T.csr_ptr[i]; s_csr_len[i] = T.csr_len[i]; }
+    for (int i = tid; i < 64 * NQ; i += nth) { s_csc_ptr[i] = T.csc_ptr[i]; s_csc_len[i] = T.csc_len[i]; }
     for (int i = tid; i < T.n_term; i += nth) { s_t_w[i] = T.t_w[i]; s_t_col[i] = T.t_col[i]; }
     for (int i = tid; i < T.n_ent; i += nth) s_e_dst[i] = T.e_dst[i];
     for (int i = tid; i <= T.n_ent; i += nth) s_e_ptr[i] = T.e_ptr[i];
     for (int i = tid; i < META_N; i += nth) s_meta[i] = T.meta[i];
     __syncthreads();
-    w.er_val = s_er_val; w.er_col = s_er_col; w.ec_val = s_ec_val; w.ec_row = s_ec_row;
+    w.csr_val = s_csr_val; w.csr_col = s_csr_col; w.csr_ptr = s_csr_ptr; w.csr_len = s_csr_len;
+    w.csc_val = s_csc_val; w.csc_row = s_csc_row; w.csc_ptr = s_csc_ptr; w.csc_len = s_csc_len;
     w.e_ptr = s_e_ptr; w.e_dst = s_e_dst; w.t_w = s_t_w; w.t_col = s_t_col; w.meta = s_meta;
-    const int wave = tid >> 6;
-    double* W0 = (double*)(lraw + T.o_wave) + (size_t)wave * T.wave_doubles;
-    w.stage = W0; w.vd = W0 + STAGE_D; w.ys = w.vd + 64 * NQ; w.bs = w.ys + G::MP; w.um = w.bs + G::MP;
-    w.rdv = w.um + G::MP; w.flr = w.rdv + G::MP; w.adv = w.flr + G::MP;
-    w.lane = tid & 63; w.q = w.lane >> 4; w.c16 = w.lane & 15;
+    wreg_carve(w, (double*)(lraw + T.o_wave) + (size_t)(tid >> 6) * T.wave_doubles, tid);
     w.m = T.m; w.n = T.n; w.rmax = T.rmax;
 }
 
@@ -423,16 +501,16 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
 // refinement of oracle newton_dy):  M dy = A(d t) - rho,  dx = d (t - A'dy),  then  e = rho - A dx;  M eta = e;
 // dx += d A'eta;  dy -= eta  while max|e| > etol, at most max_refine times.  The first solve is written as pass 0 of that
 // loop so that the kernel holds ONE copy of the (fully unrolled) block substitution.
-// In: t (per column), rho (per row), um = A(d t) - rho in LDS, the factor in w.U.  Out: dy (per row), dx, wv = A'dy.
-// Returns the refinement passes used; `bad` reports a non-finite dy.
+// In: t (per column, parked in the stage), rho (per row), um = A(d t) - rho in LDS, the factor in w.U / w.wl_().
+// Out: dy (per row), dx, wv = A'dy.  Returns the refinement passes used; `bad` reports a non-finite dy.
 template <int MB, int NQ>
 __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const double (&x)[NQ], const double (&z)[NQ],
                                             const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
                                             const double (&rho)[WGeo<MB>::MR], double etol, int max_refine,
-                                            double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ], bool& bad) {
+                                            double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ], bool& bad STAMP_ARGS) {
     constexpr int MR = WGeo<MB>::MR, MP = WGeo<MB>::MP;
     const int lane = w.lane;
-    double* vx = w.stage;
+    double* vx = w.stage_();
     double d[NQ];
 #pragma unroll
     for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] / z[qq] : 0.0;
@@ -440,41 +518,43 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const double (&x)[N
     bad = false;
     for (;;) {
         w.solve();
+        STAMP(7)
         double w2[NQ];
-        w.At(w.um, w2);
+        w.At(w.um_(), w2);
         if (pass == 0) {
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                const double tq = w.stage[lane + 64 * qq];       // t, parked there by the caller
+                const double tq = w.stage_()[lane + 64 * qq];       // t, parked there by the caller
                 wv[qq] = w2[qq];
                 dx[qq] = (tq - w2[qq]) * d[qq];
             }
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
-                dy[r2] = (lane + 64 * r2 < MP) ? w.um[lane + 64 * r2] : 0.0;
+                dy[r2] = (lane + 64 * r2 < MP) ? w.um_()[lane + 64 * r2] : 0.0;
                 bad = bad | !isfinite(dy[r2]);
             }
         } else {
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) { dx[qq] = fma(d[qq], w2[qq], dx[qq]); wv[qq] -= w2[qq]; }
 #pragma unroll
-            for (int r2 = 0; r2 < MR; r2++) dy[r2] -= (lane + 64 * r2 < MP) ? w.um[lane + 64 * r2] : 0.0;
+            for (int r2 = 0; r2 < MR; r2++) dy[r2] -= (lane + 64 * r2 < MP) ? w.um_()[lane + 64 * r2] : 0.0;
         }
         wave_lds_sync();
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = okc[qq] ? dx[qq] : 0.0;
         wave_lds_sync();
-        double Adx[MR], e[MR], me = 0.0;
-        w.Arow(vx, Adx);
+        double Adx[MR], e[MR], dummy[MR], me = 0.0;
+        w.template Arow<false>(vx, Adx, dummy);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) {
             e[r2] = okr[r2] ? rho[r2] - Adx[r2] : 0.0;
             me = fmax(me, fabs(e[r2]));
         }
         const double maxe = wmax(me);
+        STAMP(8)
         if (!(maxe > etol) || pass >= max_refine) break;
 #pragma unroll
-        for (int r2 = 0; r2 < MR; r2++) if (lane + 64 * r2 < MP) w.um[lane + 64 * r2] = e[r2];
+        for (int r2 = 0; r2 < MR; r2++) if (lane + 64 * r2 < MP) w.um_()[lane + 64 * r2] = e[r2];
         wave_lds_sync();
         pass++;
     }
@@ -501,7 +581,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     const int m = w.m, n = w.n;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
     const double nm = (double)(n + m);
-    double* vx = w.stage;
+    double* vx = w.stage_();
     bool okc[NQ], okr[MR];
 #pragma unroll
     for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
@@ -514,8 +594,8 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         if (lane == 0) nxt = atomicAdd(queue, 1);
         lp = __builtin_amdgcn_readfirstlane(nxt);
     }
+    STAMP_DECL
     while (lp < B) {
-        DBG_MARK(o, 0, lp + 1);
         double x[NQ], z[NQ];
         double c2 = 0.0;
 #pragma unroll
@@ -533,8 +613,8 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             const double bi = okr[r2] ? bg[lp * m + i] : 0.0;
             b2 = fma(bi, bi, b2);
             if (i < MP) {
-                w.bs[i] = bi;
-                w.ys[i] = okr[r2] ? ((warm && yg) ? yg[lp * m + i] : 1.0) : 0.0;
+                w.bs_()[i] = bi;
+                w.ys_()[i] = okr[r2] ? ((warm && yg) ? yg[lp * m + i] : 1.0) : 0.0;
             }
         }
         wave_lds_sync();
@@ -546,10 +626,9 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         bool running = true;
 
         while (running) {
-            DBG_MARK(o, 1, it + 1);
             // ---- sigma, gamma, objectives (primal_normal.cl:96-120, 245-248) ----
             double v[NQ], cq[NQ];
-            w.At(w.ys, v);
+            w.At(w.ys_(), v);
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
@@ -563,7 +642,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                dd += (i < MP) ? w.bs[i] * w.ys[i] : 0.0;
+                dd += (i < MP) ? w.bs_()[i] * w.ys_()[i] : 0.0;
             }
             s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
             const double norms = sqrt(s2);
@@ -576,58 +655,54 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 const double dq = okc[qq] ? x[qq] / z[qq] : 0.0;
                 t[qq] = okc[qq] ? cq[qq] - v[qq] + mu / x[qq] : 0.0;
                 vx[j] = okc[qq] ? x[qq] : 0.0;
-                w.vd[j] = dq;
+                w.vd_()[j] = dq;
             }
             wave_lds_sync();
-            double rho[MR], Ax[MR];
-            w.Arow(vx, Ax);
+            double rho[MR], Ax[MR], Md[MR];
+            w.template Arow<false>(vx, Ax, Md);
             double r2s = 0.0;
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                rho[r2] = okr[r2] ? w.bs[i] - Ax[r2] : 0.0;
+                rho[r2] = okr[r2] ? w.bs_()[i] - Ax[r2] : 0.0;
                 r2s = fma(rho[r2], rho[r2], r2s);
             }
             const double normr = sqrt(wsum(r2s));
-            DBG_MARK(o, 2, it + 1);
             // ---- stop tests (primal_normal.cl:256-269; oracle ipm_one_path) ----
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
             else if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; running = false; }
             else if (normr > 10.0 * normr0 && normr > PYCLLP_GROWTH_FLOOR * tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; running = false; }
             else if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; running = false; }
             if (running) {
-                // ---- rhs = A (d t) - rho ----
+                // ---- rhs = A (d t) - rho, diag(M) ----
                 wave_lds_sync();
 #pragma unroll
-                for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd[lane + 64 * qq] * t[qq];
+                for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd_()[lane + 64 * qq] * t[qq];
                 wave_lds_sync();
-                double Adt[MR], Md[MR];
-                w.Arow(vx, Adt);
-                w.Mdiag(Md);
+                double Adt[MR];
+                w.template Arow<true>(vx, Adt, Md);
                 double bmax = 0.0;
 #pragma unroll
                 for (int r2 = 0; r2 < MR; r2++) {
                     const int i = lane + 64 * r2;
-                    if (i < MP) w.um[i] = okr[r2] ? Adt[r2] - rho[r2] : 0.0;
+                    if (i < MP) w.um_()[i] = okr[r2] ? Adt[r2] - rho[r2] : 0.0;
                     bmax = fmax(bmax, okr[r2] ? fabs(Md[r2]) : 0.0);
                 }
                 const double beta2 = wmax(bmax);     // ldl.cl:296-311
                 wave_lds_sync();
+                STAMP(0)
                 // ---- M = A diag(d) A' into registers, t parked in the stage, factor ----
-                DBG_MARK(o, 3, it + 1);
                 w.gram();
-                DBG_MARK(o, 4, it + 1);
+                STAMP(1)
 #pragma unroll
-                for (int qq = 0; qq < NQ; qq++) w.stage[lane + 64 * qq] = t[qq];
+                for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
                 const bool viol = w.template factor<false>(beta2, o.pivot_floor, [&](auto Kc, double* tile) {
-                    w.template diag_from_tables<decltype(Kc)::value>(tile, Md); });
-                DBG_MARK(o, 5, it + 1 + (viol ? 1000 : 0));
+                    w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
                     double dy[MR], wv[NQ], dx[NQ];
                     bool bad;
-                    (void)newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad);
-                    DBG_MARK(o, 6, it + 1);
+                    (void)newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
                     if (bad) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
                     else {
                         // ---- step (primal_normal.cl:158-198) ----
@@ -643,7 +718,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
                         for (int r2 = 0; r2 < MR; r2++) {
                             const int i = lane + 64 * r2;
-                            if (i < MP) w.ys[i] = fma(theta, dy[r2], w.ys[i]);
+                            if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
                         }
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) { x[qq] = fma(theta, dx[qq], x[qq]); z[qq] = fma(theta, dz[qq], z[qq]); }
@@ -651,13 +726,12 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         wave_lds_sync();
                         it++;
                         if (it >= o.max_iter) running = false;   // status stays ITERATION_LIMIT
+                        STAMP(9)
                     }
                 }
             }
-            DBG_MARK(o, 8, it + 1);
         }
         wave_lds_sync();
-        DBG_MARK(o, 9, stat + 100);
         if (stat == -1) {   // the guard would have bitten: hand the LP to the guarded kernel
             if (lane == 0) { const int k = atomicAdd(defer, 1); defer[1 + k] = (int)lp; status[lp] = -1; }
         } else {
@@ -669,7 +743,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                if (yg && okr[r2]) yg[lp * m + i] = w.ys[i];
+                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i];
             }
             if (lane == 0) {
                 if (pobj) pobj[lp] = po;
@@ -681,7 +755,9 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(queue, 1);
         lp = __builtin_amdgcn_readfirstlane(nxt);
+        STAMP(9)
     }
+    STAMP_FLUSH(o, blockIdx.x * 4 + (threadIdx.x >> 6))
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -700,7 +776,7 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int lane = w.lane, m = w.m, n = w.n;
-    double* vx = w.stage;
+    double* vx = w.stage_();
     bool okc[NQ], okr[MR];
 #pragma unroll
     for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
@@ -720,11 +796,11 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
             const int i = lane + 64 * r2;
             const double bi = okr[r2] ? bg[lp * m + i] : 0.0;
             b2 = fma(bi, bi, b2);
-            if (i < MP) { w.bs[i] = bi; w.ys[i] = okr[r2] ? yg[lp * m + i] : 0.0; }
+            if (i < MP) { w.bs_()[i] = bi; w.ys_()[i] = okr[r2] ? yg[lp * m + i] : 0.0; }
         }
         wave_lds_sync();
         const double etol = o.refine_tol * (1.0 + sqrt(wsum(b2)));
-        w.At(w.ys, v);
+        w.At(w.ys_(), v);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             const int j = lane + 64 * qq;
@@ -733,35 +809,37 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
             const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
             t[qq] = okc[qq] ? cj - v[qq] + mu / x[qq] : 0.0;
             vx[j] = okc[qq] ? x[qq] : 0.0;
-            w.vd[j] = okc[qq] ? x[qq] / z[qq] : 0.0;
+            w.vd_()[j] = okc[qq] ? x[qq] / z[qq] : 0.0;
         }
         wave_lds_sync();
         double rho[MR], Ax[MR], Adt[MR], Md[MR];
-        w.Arow(vx, Ax);
+        w.template Arow<false>(vx, Ax, Md);
         wave_lds_sync();
 #pragma unroll
-        for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd[lane + 64 * qq] * t[qq];
+        for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd_()[lane + 64 * qq] * t[qq];
         wave_lds_sync();
-        w.Arow(vx, Adt);
-        w.Mdiag(Md);
+        w.template Arow<true>(vx, Adt, Md);
         double bmax = 0.0;
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) {
             const int i = lane + 64 * r2;
-            rho[r2] = okr[r2] ? w.bs[i] - Ax[r2] : 0.0;
-            if (i < MP) w.um[i] = okr[r2] ? Adt[r2] - rho[r2] : 0.0;
+            rho[r2] = okr[r2] ? w.bs_()[i] - Ax[r2] : 0.0;
+            if (i < MP) w.um_()[i] = okr[r2] ? Adt[r2] - rho[r2] : 0.0;
             bmax = fmax(bmax, okr[r2] ? fabs(Md[r2]) : 0.0);
         }
         const double beta2 = wmax(bmax);
         wave_lds_sync();
         w.gram();
 #pragma unroll
-        for (int qq = 0; qq < NQ; qq++) w.stage[lane + 64 * qq] = t[qq];
+        for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
+#ifdef PYCLLP_PROFILE
+        unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0};
+#endif
         (void)w.template factor<false>(beta2, o.pivot_floor, [&](auto Kc, double* tile) {
-            w.template diag_from_tables<decltype(Kc)::value>(tile, Md); });
+            w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
         double dy[MR], wv[NQ], dx[NQ];
         bool bad;
-        const int nref = newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad);
+        const int nref = newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) if (okr[r2]) dyg[lp * m + lane + 64 * r2] = dy[r2];
         if (nrefg && lane == 0) nrefg[lp] = nref;
@@ -785,32 +863,36 @@ ldl_solve_wreg_kernel(int n, long B, const double* __restrict__ Ag, const double
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
     WReg<MB, 1> w;
     USE_AGPR_FORM();
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int wave_doubles = STAGE_D + 64 + 6 * MP;
-    double* W0 = (double*)lraw + (size_t)wave * wave_doubles;
-    w.stage = W0; w.vd = W0 + STAGE_D; w.ys = w.vd + 64; w.bs = w.ys + MP; w.um = w.bs + MP; w.rdv = w.um + MP; w.flr = w.rdv + MP; w.adv = w.flr + MP;
-    w.lane = tid & 63; w.q = w.lane >> 4; w.c16 = w.lane & 15;
+    const int tid = threadIdx.x;
+    wreg_carve(w, (double*)lraw + (size_t)(tid >> 6) * G::WAVE_D(1), tid);
     const int lane = w.lane, q = w.q, c16 = w.c16;
-    for (;;) {
+    long mat;
+    {
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(queue, 1);
-        const long mat = __builtin_amdgcn_readfirstlane(nxt);
-        if (mat >= B) break;
+        mat = __builtin_amdgcn_readfirstlane(nxt);
+    }
+    while (mat < B) {
         const double* A = Ag + mat * (long)n * n;
         // off-diagonal blocks: U[K][I] register r = M[i = 16I + c16][k = 16K + 4r + q] (i > k); padded rows are zero
         static_for<0, MB>([&](auto Kc) {
             constexpr int K = decltype(Kc)::value;
             static_for<K + 1, MB>([&](auto Ic) {
                 constexpr int I = decltype(Ic)::value;
+                double4_t blk;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int i = 16 * I + c16, k = 16 * K + 4 * r + q;
-                    w.U[G::bix(K, I)][r] = (i < n) ? A[(long)i * n + k] : 0.0;
+                    blk[r] = (i < n) ? A[(long)i * n + k] : 0.0;
                 }
+                park(w.P[G::bix(K, I)], blk);
             });
         });
-        for (int i = lane; i < MP; i += 64) w.um[i] = (i < n) ? rhs[mat * n + i] : 0.0;
+        for (int i = lane; i < MP; i += 64) w.um_()[i] = (i < n) ? rhs[mat * n + i] : 0.0;
         wave_lds_sync();
+#ifdef PYCLLP_PROFILE
+        unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0};
+#endif
         // diagonal blocks come straight from memory when their turn comes: element [row][col], col <= row, of block K
         (void)w.template factor<false>(1e300, floor_, [&](auto Kc, double* tile) {
             constexpr int K = decltype(Kc)::value;
@@ -821,10 +903,13 @@ ldl_solve_wreg_kernel(int n, long B, const double* __restrict__ Ag, const double
                 if (col <= row) v = (row < n) ? A[(long)row * n + col] : ((row == col) ? 1.0 : 0.0);
                 tile[(4 * r + q) * 17 + c16] += v;
             }
-        });
+        } STAMP_PASS);
         w.solve();
-        for (int i = lane; i < n; i += 64) out[mat * n + i] = w.um[i];
+        for (int i = lane; i < n; i += 64) out[mat * n + i] = w.um_()[i];
         wave_lds_sync();
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1);
+        mat = __builtin_amdgcn_readfirstlane(nxt);
     }
 }
 
@@ -906,45 +991,35 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     int vi = -1;
     for (int i = 0; i < kNumWVariants; i++)
         if (m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
-    if (vi < 0) return 1;
+    if (vi < 0 || nnz >= 65536) return 1;
     const int MB = kWVariants[vi].mb, NQ = kWVariants[vi].nq;
-    const int MP = 16 * MB, MPL = 64 * ((MP + 63) / 64);
-    // ---- ELL by rows ----
-    int rmax = 1;
-    for (int i = 0; i < m; i++) rmax = std::max(rmax, ptr[i + 1] - ptr[i]);
-    std::vector<double> er_val((size_t)rmax * MPL, 0.0);
-    std::vector<unsigned short> er_col((size_t)rmax * MPL, 0);
-    for (int i = 0; i < m; i++)
-        for (int e = ptr[i], t = 0; e < ptr[i + 1]; e++, t++) { er_val[(size_t)t * MPL + i] = val[e]; er_col[(size_t)t * MPL + i] = (unsigned short)col[e]; }
-    // ---- CSC, ELL by columns (depth per column register) ----
+    const int MP = 16 * MB, MPL = 64 * ((MP + 63) / 64), NP = 64 * NQ;
+    WregPlan* P = new WregPlan();
+    WregTab& T = P->tab;
+    memset(&T, 0, sizeof(T));
+    T.m = m; T.n = n; T.nnz = nnz;
+    // ---- A by rows (as given) and by columns ----
+    std::vector<double> csr_val(val, val + nnz), csc_val(nnz);
+    std::vector<unsigned short> csr_col(nnz), csc_row(nnz), csr_ptr(MPL, 0), csr_len(MPL, 0), csc_ptr(NP, 0), csc_len(NP, 0);
+    int rmax = 0;
+    for (int i = 0; i < m; i++) {
+        csr_ptr[i] = (unsigned short)ptr[i]; csr_len[i] = (unsigned short)(ptr[i + 1] - ptr[i]);
+        rmax = std::max(rmax, ptr[i + 1] - ptr[i]);
+    }
+    for (int e = 0; e < nnz; e++) csr_col[e] = (unsigned short)col[e];
+    T.rmax = rmax;
     std::vector<int> cptr(n + 1, 0), crow(nnz);
-    std::vector<double> cval(nnz);
     for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
     for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
     {
         std::vector<int> fill(cptr.begin(), cptr.end() - 1);
         for (int i = 0; i < m; i++)
-            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; cval[p] = val[e]; }
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; csc_val[p] = val[e]; }
     }
-    WregPlan* P = new WregPlan();
-    WregTab& T = P->tab;
-    memset(&T, 0, sizeof(T));
-    T.m = m; T.n = n; T.rmax = rmax;
-    int ctot = 0;
-    for (int q = 0; q < NQ; q++) {
-        int cm = 0;
-        for (int j = 64 * q; j < std::min(n, 64 * q + 64); j++) cm = std::max(cm, cptr[j + 1] - cptr[j]);
-        T.meta[q] = cm; T.meta[MAX_NQ + q] = ctot; ctot += cm;
-    }
-    T.ctot = ctot;
-    std::vector<double> ec_val((size_t)std::max(ctot, 1) * 64, 0.0);
-    std::vector<unsigned short> ec_row((size_t)std::max(ctot, 1) * 64, 0);
+    for (int e = 0; e < nnz; e++) csc_row[e] = (unsigned short)crow[e];
     for (int j = 0; j < n; j++) {
-        const int q = j / 64, l = j % 64;
-        for (int e = cptr[j], t = 0; e < cptr[j + 1]; e++, t++) {
-            ec_val[(size_t)(T.meta[MAX_NQ + q] + t) * 64 + l] = cval[e];
-            ec_row[(size_t)(T.meta[MAX_NQ + q] + t) * 64 + l] = (unsigned short)crow[e];
-        }
+        csc_ptr[j] = (unsigned short)cptr[j]; csc_len[j] = (unsigned short)(cptr[j + 1] - cptr[j]);
+        T.meta[j / 64] = std::max(T.meta[j / 64], cptr[j + 1] - cptr[j]);
     }
     // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk, then the entries
     //      inside the diagonal blocks grouped by block ----
@@ -960,10 +1035,10 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
                 const int i = crow[a], k = crow[b2];   // rows ascend inside a column: i > k
                 const int K = k / 16, I = i / 16;
                 if (I == K) {          // diagonal block K: element [i%16][k%16] of the stride-17 tile
-                    terms.push_back({nchunk + K, (i % 16) * 17 + (k % 16), j, cval[a] * cval[b2]});
+                    terms.push_back({nchunk + K, (i % 16) * 17 + (k % 16), j, csc_val[a] * csc_val[b2]});
                 } else {               // block (K, I) of U: element [k%16][i%16], block (I-K-1) % HB of its chunk
                     const int ch = (I - K - 1) / HB, bi = (I - K - 1) % HB;
-                    terms.push_back({chbase[K] + ch, bi * 256 + (k % 16) * 16 + (i % 16), j, cval[a] * cval[b2]});
+                    terms.push_back({chbase[K] + ch, bi * 256 + (k % 16) * 16 + (i % 16), j, csc_val[a] * csc_val[b2]});
                 }
                 if (terms.size() > ((size_t)1 << 22)) { delete P; return 1; }
             }
@@ -990,32 +1065,39 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     // ---- LDS plan ----
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 15) & ~(size_t)15; const size_t o_ = off; off += bytes; return (int)o_; };
-    T.o_er_val = take(sizeof(double) * er_val.size());
-    T.o_ec_val = take(sizeof(double) * ec_val.size());
+    T.o_csr_val = take(sizeof(double) * csr_val.size());
+    T.o_csc_val = take(sizeof(double) * csc_val.size());
     T.o_t_w = take(sizeof(double) * t_w.size());
-    T.wave_doubles = STAGE_D + 64 * NQ + 6 * MP;
+    T.wave_doubles = STAGE_D + 64 * NQ + 6 * MP + MB * WL;
     T.o_wave = take(sizeof(double) * 4 * (size_t)T.wave_doubles);
     T.o_e_ptr = take(sizeof(unsigned) * e_ptr.size());
     T.o_meta = take(sizeof(int) * META_N);
-    T.o_er_col = take(sizeof(unsigned short) * er_col.size());
-    T.o_ec_row = take(sizeof(unsigned short) * ec_row.size());
+    T.o_csr_col = take(sizeof(unsigned short) * csr_col.size());
+    T.o_csr_ptr = take(sizeof(unsigned short) * csr_ptr.size());
+    T.o_csr_len = take(sizeof(unsigned short) * csr_len.size());
+    T.o_csc_row = take(sizeof(unsigned short) * csc_row.size());
+    T.o_csc_ptr = take(sizeof(unsigned short) * csc_ptr.size());
+    T.o_csc_len = take(sizeof(unsigned short) * csc_len.size());
     T.o_e_dst = take(sizeof(unsigned short) * e_dst.size());
     T.o_t_col = take(sizeof(unsigned short) * t_col.size());
     T.lds_bytes = (int)((off + 15) & ~(size_t)15);
     if (T.lds_bytes > max_lds) { delete P; return 1; }
     // ---- device copies ----
     std::vector<char> host;
-    const size_t a1 = put(host, er_val), a2 = put(host, ec_val), a3 = put(host, t_w), a4 = put(host, e_ptr),
-                 a5 = put(host, er_col), a6 = put(host, ec_row), a7 = put(host, e_dst), a8 = put(host, t_col);
+    const size_t a1 = put(host, csr_val), a2 = put(host, csc_val), a3 = put(host, t_w), a4 = put(host, e_ptr),
+                 a5 = put(host, csr_col), a6 = put(host, csr_ptr), a7 = put(host, csr_len), a8 = put(host, csc_row),
+                 a9 = put(host, csc_ptr), a10 = put(host, csc_len), a11 = put(host, e_dst), a12 = put(host, t_col);
     hipError_t e = hipMalloc(&P->dev_blob, host.size());
     if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { if (P->dev_blob) (void)hipFree(P->dev_blob); delete P; return 1000 + (int)e; }
     char* db = (char*)P->dev_blob;
-    T.er_val = (const double*)(db + a1); T.ec_val = (const double*)(db + a2); T.t_w = (const double*)(db + a3);
-    T.e_ptr = (const unsigned*)(db + a4); T.er_col = (const unsigned short*)(db + a5);
-    T.ec_row = (const unsigned short*)(db + a6); T.e_dst = (const unsigned short*)(db + a7);
-    T.t_col = (const unsigned short*)(db + a8);
+    T.csr_val = (const double*)(db + a1); T.csc_val = (const double*)(db + a2); T.t_w = (const double*)(db + a3);
+    T.e_ptr = (const unsigned*)(db + a4);
+    T.csr_col = (const unsigned short*)(db + a5); T.csr_ptr = (const unsigned short*)(db + a6);
+    T.csr_len = (const unsigned short*)(db + a7); T.csc_row = (const unsigned short*)(db + a8);
+    T.csc_ptr = (const unsigned short*)(db + a9); T.csc_len = (const unsigned short*)(db + a10);
+    T.e_dst = (const unsigned short*)(db + a11); T.t_col = (const unsigned short*)(db + a12);
     P->mb = MB; P->nq = NQ;
     *out = P;
     return 0;
@@ -1073,7 +1155,7 @@ hipError_t wreg_launch_ldl_solve(int n, long B, const double* A, const double* r
     e = hipMemsetAsync(qhead, 0, sizeof(int), st);
     long grid = std::min((long)num_cu, (B + 3) / 4);
     if (grid < 1) grid = 1;
-    const int lds = (int)(sizeof(double) * 4 * (STAGE_D + 64 + 6 * 128));
+    const int lds = (int)(sizeof(double) * 4 * WGeo<8>::WAVE_D(1));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ldl_solve_wreg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL((ldl_solve_wreg_kernel<8>), dim3((unsigned)grid), dim3(256), lds, st, n, B, A, rhs, out, floor_, qhead);
