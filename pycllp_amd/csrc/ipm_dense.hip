@@ -989,7 +989,7 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
     HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     int* worklist = nullptr;
-    const bool use_wreg = h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_HSD | PYCLLP_FLAG_AUTOSCALE));
+    const bool use_wreg = h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_AUTOSCALE));
     h->last_wreg = use_wreg ? 1 : 0;
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path

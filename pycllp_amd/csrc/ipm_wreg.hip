@@ -126,6 +126,11 @@ __device__ __forceinline__ double row_max(double v) {
     v = fmax(v, dpp_d<0x140>(v));
     return v;
 }
+// a wave-uniform double, moved to a scalar register pair: the f64 arithmetic that produced it left it in VGPRs, where a
+// kernel-lifetime scalar (tolerances, mu, theta, ...) costs two registers of every lane -- or a scratch slot
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 // whole-wave reductions: DPP inside the rows, then the four row results through SGPRs (wave-uniform result)
 __device__ __forceinline__ double wsum(double v) {
     v = row_sum(v);
@@ -513,7 +518,7 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const double (&x)[N
     double* vx = w.stage_();
     double d[NQ];
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] / z[qq] : 0.0;
+    for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
     int pass = 0;
     bad = false;
     for (;;) {
@@ -619,8 +624,8 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         }
         wave_lds_sync();
         const double nb2 = wsum(b2), nc2 = wsum(c2);
-        const double tol_r = o.eps * (1.0 + sqrt(nb2)), tol_s = o.eps * (1.0 + sqrt(nc2));
-        const double etol = o.refine_tol * (1.0 + sqrt(nb2));
+        const double tol_r = uni(o.eps * (1.0 + sqrt(nb2))), tol_s = uni(o.eps * (1.0 + sqrt(nc2)));
+        const double etol = uni(o.refine_tol * (1.0 + sqrt(nb2)));
         double normr0 = 1e300, norms0 = 1e300, po = 0.0, du = 0.0;
         int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
         bool running = true;
@@ -645,15 +650,15 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 dd += (i < MP) ? w.bs_()[i] * w.ys_()[i] : 0.0;
             }
             s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
-            const double norms = sqrt(s2);
-            const double mu = o.delta * gam / nm;
+            const double norms = uni(sqrt(s2));
+            const double mu = uni(o.delta * gam / nm);
             // ---- d, t; rho = b - A x (primal_normal.cl:50-74) ----
             double t[NQ];
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
                 const int j = lane + 64 * qq;
-                const double dq = okc[qq] ? x[qq] / z[qq] : 0.0;
-                t[qq] = okc[qq] ? cq[qq] - v[qq] + mu / x[qq] : 0.0;
+                const double dq = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;      // v_rcp_f64 + 2 Newton steps (<= 2 ulp), as
+                t[qq] = okc[qq] ? cq[qq] - v[qq] + mu * fast_rcp(x[qq]) : 0.0;   // the dense group kernel
                 vx[j] = okc[qq] ? x[qq] : 0.0;
                 w.vd_()[j] = dq;
             }
@@ -667,7 +672,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 rho[r2] = okr[r2] ? w.bs_()[i] - Ax[r2] : 0.0;
                 r2s = fma(rho[r2], rho[r2], r2s);
             }
-            const double normr = sqrt(wsum(r2s));
+            const double normr = uni(sqrt(wsum(r2s)));
             // ---- stop tests (primal_normal.cl:256-269; oracle ipm_one_path) ----
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
             else if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; running = false; }
@@ -709,11 +714,12 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         double dz[NQ], th = 0.0;
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) {
-                            dz[qq] = okc[qq] ? (mu - z[qq] * dx[qq]) / x[qq] - z[qq] : 0.0;
-                            if (okc[qq]) th = fmax(th, fmax(-dz[qq] / z[qq], -dx[qq] / x[qq]));
+                            const double rx = fast_rcp(x[qq]), rz = fast_rcp(z[qq]);
+                            dz[qq] = okc[qq] ? (mu - z[qq] * dx[qq]) * rx - z[qq] : 0.0;
+                            if (okc[qq]) th = fmax(th, fmax(-dz[qq] * rz, -dx[qq] * rx));
                         }
                         th = wmax(th);
-                        const double theta = fmin(o.r / th, 1.0);
+                        const double theta = uni(fmin(o.r / th, 1.0));
                         wave_lds_sync();
 #pragma unroll
                         for (int r2 = 0; r2 < MR; r2++) {
@@ -748,6 +754,306 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             if (lane == 0) {
                 if (pobj) pobj[lp] = po;
                 if (dobj) dobj[lp] = du;
+                status[lp] = stat;
+                if (iters) iters[lp] = it;
+            }
+        }
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1);
+        lp = __builtin_amdgcn_readfirstlane(nxt);
+        STAMP(9)
+    }
+    STAMP_FLUSH(o, blockIdx.x * 4 + (threadIdx.x >> 6))
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the same solve on the homogeneous self-dual embedding (PYCLLP_FLAG_HSD; oracle hsd_one_raw, ipm_block_kernel's run-time
+// branch, csrc/ipm_group_hsd.inc): tau and kappa are wave-uniform scalars, one factorisation serves the two right-hand
+// sides  M p = A(d c) - b  and  M q = A(d r1) - eta rho, the pivot floor of column j is pivot_floor^2 |M_jj|
+// ------------------------------------------------------------------------------------------------------------------
+template <int MB, int NQ>
+__global__ void __launch_bounds__(256, 1)
+hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg,
+                double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
+                double* __restrict__ dobj, int* __restrict__ status, int* __restrict__ iters, int* __restrict__ queue,
+                int* __restrict__ defer, DevOpts o) {
+    using G = WGeo<MB>;
+    constexpr int MR = G::MR, MP = G::MP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
+    WReg<MB, NQ> w;
+    USE_AGPR_FORM();
+    wreg_setup(w, T, lraw, threadIdx.x);
+    const int lane = w.lane;
+    const int m = w.m, n = w.n;
+    const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+    const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
+    double* vx = w.stage_();
+    double* pv = w.flr_();          // p = M^-1 (A(d c) - b): the floor vector is dead once the factor exists
+    bool okc[NQ], okr[MR];
+#pragma unroll
+    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
+#pragma unroll
+    for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
+
+    long lp;
+    {
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(queue, 1);
+        lp = __builtin_amdgcn_readfirstlane(nxt);
+    }
+    STAMP_DECL
+    while (lp < B) {
+        double x[NQ], z[NQ];
+        double c2 = 0.0, g0 = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) {
+            const int j = lane + 64 * qq;
+            const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
+            c2 = fma(cj, cj, c2);
+            x[qq] = (warm && okc[qq]) ? xg[lp * n + j] : 1.0;
+            z[qq] = (warm && okc[qq]) ? zg[lp * n + j] : 1.0;
+            g0 += okc[qq] ? x[qq] * z[qq] : 0.0;
+        }
+        double b2 = 0.0;
+#pragma unroll
+        for (int r2 = 0; r2 < MR; r2++) {
+            const int i = lane + 64 * r2;
+            const double bi = okr[r2] ? bg[lp * m + i] : 0.0;
+            b2 = fma(bi, bi, b2);
+            if (i < MP) {
+                w.bs_()[i] = bi;
+                w.ys_()[i] = (okr[r2] && warm && yg) ? yg[lp * m + i] : 0.0;
+            }
+        }
+        wave_lds_sync();
+        const double nbn = uni(sqrt(wsum(b2))), ncn = uni(sqrt(wsum(c2)));
+        const double tol_r = uni(o.eps * (1.0 + nbn)), tol_s = uni(o.eps * (1.0 + ncn));
+        double tau = 1.0, kap = 1.0;
+        if (warm) kap = uni(wsum(g0) / (double)n);
+        double po = 0.0, du = 0.0;
+        int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
+        bool running = true;
+
+        while (running) {
+            // ---- sigma = c tau - A'y + z, gamma, objectives ----
+            double v[NQ], cq[NQ], sg[NQ];
+            w.At(w.ys_(), v);
+            double s2 = 0.0, gam = 0.0, pp = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                cq[qq] = okc[qq] ? cg[lp * n + lane + 64 * qq] : 0.0;
+                sg[qq] = okc[qq] ? cq[qq] * tau - v[qq] + z[qq] : 0.0;
+                s2 = fma(sg[qq], sg[qq], s2);
+                gam += okc[qq] ? x[qq] * z[qq] : 0.0;
+                pp += cq[qq] * (okc[qq] ? x[qq] : 0.0);
+            }
+            double dd = 0.0;
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const int i = lane + 64 * r2;
+                dd += (i < MP) ? w.bs_()[i] * w.ys_()[i] : 0.0;
+            }
+            s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
+            const double norms = uni(sqrt(s2));
+            const double mu = uni(o.delta * (gam + tau * kap) / (double)(n + 1));
+            const double phi = uni(du - po + kap);
+            // ---- d, t = r1 = mu/x - z + eta sigma; rho = b tau - A x ----
+            double t[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                const int j = lane + 64 * qq;
+                const double dq = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
+                t[qq] = okc[qq] ? fma(eta, sg[qq], mu * fast_rcp(x[qq]) - z[qq]) : 0.0;
+                vx[j] = okc[qq] ? x[qq] : 0.0;
+                w.vd_()[j] = dq;
+            }
+            wave_lds_sync();
+            double rho[MR], Ax[MR], Md[MR];
+            w.template Arow<false>(vx, Ax, Md);
+            double r2s = 0.0;
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const int i = lane + 64 * r2;
+                rho[r2] = okr[r2] ? w.bs_()[i] * tau - Ax[r2] : 0.0;
+                r2s = fma(rho[r2], rho[r2], r2s);
+            }
+            const double normr = uni(sqrt(wsum(r2s)));
+            // ---- stop tests (oracle hsd_one_raw): optimal, or a primal / dual ray ----
+            const bool p_ray = po > 0.0 && fma(nbn, tau, normr) <= einf * po;
+            const bool d_ray = du < 0.0 && fma(ncn, tau, norms) <= einf * -du;
+            if (!(isfinite(normr) && isfinite(norms) && isfinite(gam) && isfinite(tau) && isfinite(kap))) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
+            else if (normr <= tol_r * tau && norms <= tol_s * tau && gam <= o.eps * tau * (tau + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; running = false; }
+            else if (p_ray || d_ray) {
+                stat = (p_ray && d_ray) ? ((-du > po) ? PYCLLP_STATUS_PRIMAL_INFEASIBLE : PYCLLP_STATUS_DUAL_INFEASIBLE)
+                                        : (p_ray ? PYCLLP_STATUS_DUAL_INFEASIBLE : PYCLLP_STATUS_PRIMAL_INFEASIBLE);
+                running = false;
+            }
+            if (running) {
+                // ---- A(d r1), diag(M), A(d c) ----
+                wave_lds_sync();
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd_()[lane + 64 * qq] * t[qq];
+                wave_lds_sync();
+                double Adt[MR], Adc[MR], dummy[MR];
+                w.template Arow<true>(vx, Adt, Md);
+                wave_lds_sync();
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd_()[lane + 64 * qq] * cq[qq];
+                wave_lds_sync();
+                w.template Arow<false>(vx, Adc, dummy);
+                double rq[MR], bmax = 0.0;
+#pragma unroll
+                for (int r2 = 0; r2 < MR; r2++) {
+                    const int i = lane + 64 * r2;
+                    rq[r2] = okr[r2] ? fma(-eta, rho[r2], Adt[r2]) : 0.0;
+                    if (i < MP) {
+                        w.um_()[i] = okr[r2] ? Adc[r2] - w.bs_()[i] : 0.0;                   // right-hand side of p
+                        w.flr_()[i] = o.pivot_floor * o.pivot_floor * fabs(Md[r2]);         // floor of column i
+                    }
+                    bmax = fmax(bmax, okr[r2] ? fabs(Md[r2]) : 0.0);
+                }
+                const double beta2 = uni(wmax(bmax));
+                wave_lds_sync();
+                STAMP(0)
+                w.gram();
+                STAMP(1)
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
+                const bool viol = w.template factor<true>(beta2, 0.0, [&](auto Kc, double* tile) {
+                    w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
+                if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
+                else {
+                    // ---- one loop around the ONE copy of the block substitution: pass 0 solves for p, pass 1 for q and
+                    //      combines them through dtau, the following passes are the x-space refinement ----
+                    double d[NQ], dx[NQ], u[NQ] /* c - A'p */, dy[MR], rhot[MR];
+#pragma unroll
+                    for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
+                    double dtau = 0.0, etol_it = 0.0;
+                    bool bad = false;
+                    int pass = 0;
+                    for (;;) {
+                        w.solve();
+                        STAMP(7)
+                        double w2[NQ];
+                        w.At(w.um_(), w2);
+                        bool more = true;
+                        if (pass == 0) {
+                            // c - A'p is kept; p moves to pv, q's right-hand side into um
+#pragma unroll
+                            for (int qq = 0; qq < NQ; qq++) u[qq] = cq[qq] - w2[qq];
+                            wave_lds_sync();
+#pragma unroll
+                            for (int r2 = 0; r2 < MR; r2++) {
+                                const int i = lane + 64 * r2;
+                                if (i < MP) { pv[i] = w.um_()[i]; w.um_()[i] = rq[r2]; }
+                            }
+                            wave_lds_sync();
+                        } else {
+                            if (pass == 1) {
+                                double dsum = 0.0, nsum = 0.0, bq = 0.0;
+#pragma unroll
+                                for (int qq = 0; qq < NQ; qq++) {
+                                    const double tq = w.stage_()[lane + 64 * qq];
+                                    dx[qq] = d[qq] * (tq - w2[qq]);                       // v = d (r1 - A'q)
+                                    dsum = fma(d[qq] * u[qq], u[qq], dsum);               // |sqrt(d)(c - A'p)|^2
+                                    nsum = fma(cq[qq], dx[qq], nsum);                     // c'v
+                                }
+#pragma unroll
+                                for (int r2 = 0; r2 < MR; r2++) {
+                                    const int i = lane + 64 * r2;
+                                    bq += (i < MP) ? w.bs_()[i] * w.um_()[i] : 0.0;       // b'q
+                                }
+                                const double den = wsum(dsum) + kap / tau;
+                                const double num = fma(eta, phi, mu / tau - kap) + wsum(bq) - wsum(nsum);
+                                dtau = uni(num / den);
+#pragma unroll
+                                for (int r2 = 0; r2 < MR; r2++) {
+                                    const int i = lane + 64 * r2;
+                                    dy[r2] = (i < MP) ? fma(pv[i], dtau, w.um_()[i]) : 0.0;
+                                    rhot[r2] = okr[r2] ? fma(w.bs_()[i], dtau, eta * rho[r2]) : 0.0;   // A dx - b dtau = eta rho
+                                    bad = bad | !isfinite(dy[r2]);
+                                }
+#pragma unroll
+                                for (int qq = 0; qq < NQ; qq++) dx[qq] = fma(d[qq] * u[qq], dtau, dx[qq]);   // dx = u dtau + v, u = d (c - A'p)
+                                etol_it = uni(o.refine_tol * (1.0 + nbn) * fmax(tau, kap));
+                            } else {
+#pragma unroll
+                                for (int qq = 0; qq < NQ; qq++) dx[qq] = fma(d[qq], w2[qq], dx[qq]);
+#pragma unroll
+                                for (int r2 = 0; r2 < MR; r2++) dy[r2] -= (lane + 64 * r2 < MP) ? w.um_()[lane + 64 * r2] : 0.0;
+                            }
+                            wave_lds_sync();
+#pragma unroll
+                            for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = okc[qq] ? dx[qq] : 0.0;
+                            wave_lds_sync();
+                            double Adx[MR], e[MR], dm[MR], me = 0.0;
+                            w.template Arow<false>(vx, Adx, dm);
+#pragma unroll
+                            for (int r2 = 0; r2 < MR; r2++) {
+                                e[r2] = okr[r2] ? rhot[r2] - Adx[r2] : 0.0;
+                                me = fmax(me, fabs(e[r2]));
+                            }
+                            const double maxe = wmax(me);
+                            STAMP(8)
+                            if (!(maxe > etol_it) || pass - 1 >= o.max_refine) more = false;
+                            else {
+#pragma unroll
+                                for (int r2 = 0; r2 < MR; r2++) if (lane + 64 * r2 < MP) w.um_()[lane + 64 * r2] = e[r2];
+                                wave_lds_sync();
+                            }
+                        }
+                        if (!more) break;
+                        pass++;
+                    }
+                    if (__any(bad) || !isfinite(dtau)) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
+                    else {
+                        // ---- step: ratio test over x, z, tau, kappa ----
+                        const double dkap = mu / tau - kap - kap / tau * dtau;
+                        double dz[NQ], th = fmax(fmax(-dtau / tau, -dkap / kap), 0.0);
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) {
+                            const double rx = fast_rcp(x[qq]), rz = fast_rcp(z[qq]);
+                            dz[qq] = okc[qq] ? (mu - z[qq] * dx[qq]) * rx - z[qq] : 0.0;
+                            if (okc[qq]) th = fmax(th, fmax(-dz[qq] * rz, -dx[qq] * rx));
+                        }
+                        th = wmax(th);
+                        const double theta = uni(fmin(o.r / th, 1.0));
+                        wave_lds_sync();
+#pragma unroll
+                        for (int r2 = 0; r2 < MR; r2++) {
+                            const int i = lane + 64 * r2;
+                            if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) { x[qq] = fma(theta, dx[qq], x[qq]); z[qq] = fma(theta, dz[qq], z[qq]); }
+                        tau = uni(fma(theta, dtau, tau)); kap = uni(fma(theta, dkap, kap));
+                        wave_lds_sync();
+                        it++;
+                        if (it >= o.max_iter) running = false;
+                        STAMP(9)
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        if (stat == -1) {
+            if (lane == 0) { const int k = atomicAdd(defer, 1); defer[1 + k] = (int)lp; status[lp] = -1; }
+        } else {
+            // optimal (and iteration-limit) points leave the homogeneous scaling (hsd.c:266-273); certificates stay
+            const double rt = (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT) ? 1.0 / tau : 1.0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                const int j = lane + 64 * qq;
+                if (okc[qq]) { xg[lp * n + j] = x[qq] * rt; if (zg) zg[lp * n + j] = z[qq] * rt; }
+            }
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const int i = lane + 64 * r2;
+                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i] * rt;
+            }
+            if (lane == 0) {
+                if (pobj) pobj[lp] = po * rt;
+                if (dobj) dobj[lp] = du * rt;
                 status[lp] = stat;
                 if (iters) iters[lp] = it;
             }
@@ -807,9 +1113,9 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
             x[qq] = okc[qq] ? xg[lp * n + j] : 1.0;
             z[qq] = okc[qq] ? zg[lp * n + j] : 1.0;
             const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
-            t[qq] = okc[qq] ? cj - v[qq] + mu / x[qq] : 0.0;
+            t[qq] = okc[qq] ? cj - v[qq] + mu * fast_rcp(x[qq]) : 0.0;
             vx[j] = okc[qq] ? x[qq] : 0.0;
-            w.vd_()[j] = okc[qq] ? x[qq] / z[qq] : 0.0;
+            w.vd_()[j] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
         }
         wave_lds_sync();
         double rho[MR], Ax[MR], Adt[MR], Md[MR];
@@ -969,6 +1275,16 @@ hipError_t do_solve(const WregTab& T, long B, const double* b, const double* c, 
     return hipGetLastError();
 }
 template <int MB, int NQ>
+hipError_t do_solve_hsd(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
+                        double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
+                        hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute((const void*)hsd_wreg_kernel<MB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ>), dim3(grid), dim3(256), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
+                       status, iters, qhead, defer, o);
+    return hipGetLastError();
+}
+template <int MB, int NQ>
 hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z, const double* y, const double* b,
                      const double* c, double mu, double* dy, int* nref, int* qhead, DevOpts o, int grid, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)newton_wreg_kernel<MB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
@@ -978,8 +1294,8 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
     return hipGetLastError();
 }
 
-struct WVariant { int mb, nq; wsolve_fn solve; wnewton_fn newton; };
-#define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_newton<MB, NQ> }
+struct WVariant { int mb, nq; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
+#define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_solve_hsd<MB, NQ>, do_newton<MB, NQ> }
 // ordered by cost; the first variant with 16 mb >= m and 64 nq >= n is used
 const WVariant kWVariants[] = { WVARIANT(8, 6) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
@@ -1128,7 +1444,7 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* b, const double*
     long grid = std::min(cus, (B + 3) / 4);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
-    return v->solve(p->tab, B, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
+    return ((o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve)(p->tab, B, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
 }
 
 hipError_t wreg_launch_newton(WregPlan* p, long B, const double* x, const double* z, const double* y, const double* b,

@@ -65,17 +65,17 @@ def newton(m=128, n=256, B=32, density=0.025):
     print("newton (%d,%d) rc=%d rel err %.2e nref max %d" % (m, n, rc, err, int(nref.max())))
     return rc == 0 and err < 1e-7
 
-def full(m=128, n=256, B=256, density=0.025, flags=0):
+def full(m=128, n=256, B=256, density=0.025, flags=0, hsd=False):
     A, b, c = problems.random_sparse_arrays(m, n, B, density=density, seed=0)
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
-    s = solver_registry["hip_sparse_primal_normal"](device=dev, flags=flags)
+    s = solver_registry["hip_sparse_primal_normal"](device=dev, flags=flags, hsd=hsd)
     lp.init(s)
     t0 = time.time(); st = lp.solve(s); dt = time.time() - t0
     Ae = np.hstack([A.toarray(), np.eye(m)]); ce = np.hstack([c, np.zeros((B, m))])
-    ref = port.dense_solve(Ae, b, ce, nthreads=16)
+    ref = port.dense_solve(Ae, b, ce, nthreads=16, flags=32 if hsd else 0)
     err = np.abs(s.primal_obj - ref["pobj"]) / np.maximum(1, np.abs(ref["pobj"]))
-    print("full flags=%d B=%d: status0 %d/%d, iters equal %s (max diff %d), max obj err %.2e, %.3fs"
-          % (flags, B, int((st == 0).sum()), B, np.array_equal(s.iters, ref["iters"]),
+    print("full hsd=%s flags=%d B=%d: status0 %d/%d, iters equal %s (max diff %d), max obj err %.2e, %.3fs"
+          % (hsd, flags, B, int((st == 0).sum()), B, np.array_equal(s.iters, ref["iters"]),
              int(np.abs(s.iters - ref["iters"]).max()), err.max(), dt))
     return (st == 0).all() and err.max() < 1e-9
 
@@ -100,6 +100,7 @@ if __name__ == "__main__":
     if "newton" in what: ok &= newton()
     if "full" in what:
         ok &= full(flags=64, B=64); ok &= full(flags=0, B=256); ok &= full(flags=4, B=32)
+        ok &= full(flags=0, B=256, hsd=True); ok &= full(flags=64, B=64, hsd=True)
     if "timing" in what:
-        timing(flags=64); timing(flags=0); timing(flags=64, hsd=True)
+        timing(flags=0); timing(flags=0, hsd=True)
     print("BRINGUP", "OK" if ok else "FAILED")
