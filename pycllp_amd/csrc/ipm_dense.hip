@@ -561,6 +561,7 @@ struct pycllp_hip_dense {
     int grid, block, lds;
     int num_cu;
     int max_lds;
+    struct pycllp_hip_sparse* sp;   // LPs beyond the lane-group kernels (m <= 128, n <= 512): served by the sparse path's kernels
 };
 
 typedef hipError_t (*solve_launch_fn)(pycllp_hip_dense*, long, const double*, const double*, double*, double*,
@@ -736,8 +737,8 @@ void pycllp_hip_default_opts(pycllp_hip_opts* o) {
     o->reserve_cus = 0;
 }
 
-int pycllp_hip_dense_max_rows(void) { return 32; }
-int pycllp_hip_dense_max_cols(void) { return 128; }
+int pycllp_hip_dense_max_rows(void) { return BLK_MAX_M; }   // m <= 32, n <= 128: lane-group kernels; beyond: the sparse path's kernels
+int pycllp_hip_dense_max_cols(void) { return BLK_MAX_N; }
 
 int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycllp_hip_dense** handle) {
     if (!A_dev || !handle || m <= 0 || n <= 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_init: bad argument");
@@ -745,8 +746,42 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
     for (int i = 0; i < kNumVariants; i++)
         if (m <= kVariants[i].mp && n <= kVariants[i].np) { vi = i; break; }
     if (vi < 0) {
-        snprintf(g_err, sizeof(g_err), "pycllp_hip_dense_init: (m=%d, n=%d) exceeds the compiled kernels (m<=32, n<=128)", m, n);
-        return PYCLLP_E_UNSUPPORTED;
+        // Beyond the lane-group kernels (m <= 32, n <= 128).  The reference's dense host has no size limit
+        // (pycllp/solvers/cl.py:28-83; its own kernel test runs m = 100, N = 180): up to m = 128, n = 512 the LP is handed
+        // to the kernels of the sparse path -- the structural non-zeros of the dense A become its CSR arrays.
+        if (m > BLK_MAX_M || n > BLK_MAX_N) {
+            snprintf(g_err, sizeof(g_err), "pycllp_hip_dense_init: (m=%d, n=%d) exceeds the compiled kernels (m<=%d, n<=%d)", m, n,
+                     BLK_MAX_M, BLK_MAX_N);
+            return PYCLLP_E_UNSUPPORTED;
+        }
+        hipStream_t st = (hipStream_t)stream;
+        std::vector<double> Ah((size_t)m * n);
+        HIP_TRY(hipMemcpyAsync(Ah.data(), A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<double> val; std::vector<int> ptr(m + 1, 0), col;
+        for (int i = 0; i < m; i++) {
+            for (int j = 0; j < n; j++) if (Ah[(size_t)i * n + j] != 0.0) { val.push_back(Ah[(size_t)i * n + j]); col.push_back(j); }
+            ptr[i + 1] = (int)val.size();
+        }
+        if (val.empty()) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_init: A is all zero");
+        double* dval = nullptr; int* dptr = nullptr; int* dcol = nullptr;
+        hipError_t e = hipMalloc((void**)&dval, sizeof(double) * val.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&dptr, sizeof(int) * ptr.size());
+        if (e == hipSuccess) e = hipMalloc((void**)&dcol, sizeof(int) * col.size());
+        if (e == hipSuccess) e = hipMemcpyAsync(dval, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dptr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(dcol, col.data(), sizeof(int) * col.size(), hipMemcpyHostToDevice, st);
+        pycllp_hip_sparse* sp = nullptr;
+        int rc = (e == hipSuccess) ? pycllp_hip_sparse_init(m, n, (int)val.size(), dval, dptr, dcol, stream, &sp) : set_err((int)e, "upload CSR of the dense A");
+        if (dval) (void)hipFree(dval);
+        if (dptr) (void)hipFree(dptr);
+        if (dcol) (void)hipFree(dcol);
+        if (rc != 0) return rc;
+        pycllp_hip_dense* hs = (pycllp_hip_dense*)calloc(1, sizeof(pycllp_hip_dense));
+        if (!hs) { pycllp_hip_sparse_free(sp); return set_err(PYCLLP_E_NOMEM, "pycllp_hip_dense_init: out of host memory"); }
+        hs->m = m; hs->n = n; hs->variant = -1; hs->variant_sl = -1; hs->sp = sp;
+        *handle = hs;
+        return 0;
     }
     pycllp_hip_dense* h = (pycllp_hip_dense*)calloc(1, sizeof(pycllp_hip_dense));
     if (!h) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_dense_init: out of host memory");
@@ -798,6 +833,15 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
     if (B == 0) return 0;  // empty batch: nothing to do (pointers may be NULL)
     if (!b_dev || !c_dev || !x_dev || !status_dev)
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: bad argument");
+    if (h->sp) {   // beyond the lane-group kernels: the sparse path's kernels (flags that select lane-group variants do not apply)
+        pycllp_hip_opts so;
+        pycllp_hip_default_opts(&so);
+        if (opts) so = *opts;
+        if (so.flags & PYCLLP_FLAG_WAVE_KERNEL)
+            return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_WAVE_KERNEL is not available beyond m = 32, n = 128");
+        so.flags &= ~PYCLLP_FLAG_NO_SLACK_PATH;
+        return pycllp_hip_sparse_solve(h->sp, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, &so, stream);
+    }
     DevOpts o = to_dev(opts);
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: warm start needs y_dev and z_dev");
@@ -824,6 +868,7 @@ int pycllp_hip_dense_newton(pycllp_hip_dense* h, long B, const double* x_dev, co
     if (B == 0) return 0;
     if (!x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev)
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_newton: bad argument");
+    if (h->sp) return pycllp_hip_sparse_newton(h->sp, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, opts, stream);
     DevOpts o = to_dev(opts);
     hipError_t e = kVariants[h->variant].newton(h, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o,
                                                 (hipStream_t)stream);
@@ -834,6 +879,13 @@ int pycllp_hip_dense_newton(pycllp_hip_dense* h, long B, const double* x_dev, co
 int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* block, int* lds_bytes, int* m_pad,
                                  int* n_pad) {
     if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_launch_info: bad argument");
+    if (h->sp) {
+        int kern = 0;
+        const int rc = pycllp_hip_sparse_launch_info(h->sp, grid, block, lds_bytes, &kern);
+        if (m_pad) *m_pad = BLK_MAX_M;
+        if (n_pad) *n_pad = BLK_MAX_N;
+        return rc;
+    }
     if (grid) *grid = h->grid;
     if (block) *block = h->block;
     if (lds_bytes) *lds_bytes = h->lds;
@@ -1006,7 +1058,7 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     if (blocks > B) blocks = B;
     if (!use_wreg) h->grid = (int)blocks;
     hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
-                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, o);
+                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, o);
     hipError_t e = hipGetLastError();
     if (worklist) { hipError_t e2 = hipFreeAsync(worklist, st); if (e == hipSuccess) e = e2; }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
@@ -1020,15 +1072,25 @@ int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, 
     if (B == 0) return 0;
     if (!x_dev || !z_dev || !y_dev || !b_dev || !c_dev || !dy_dev)
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_newton: bad argument");
-    if (!h->wreg) {
-        snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_newton: the stand-alone step needs the register-resident kernel, "
-                 "which does not cover this matrix (m=%d, n=%d)", h->desc.m, h->desc.n);
-        return PYCLLP_E_UNSUPPORTED;
-    }
     DevOpts o = to_dev(opts);
-    hipError_t e = wreg_launch_newton(h->wreg, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o, h->num_cu,
-                                      (hipStream_t)stream);
-    if (e != hipSuccess) return set_err((int)e, "newton_wreg_kernel launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (h->wreg && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL)) {
+        hipError_t e = wreg_launch_newton(h->wreg, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o, h->num_cu, st);
+        if (e != hipSuccess) return set_err((int)e, "newton_wreg_kernel launch");
+        return 0;
+    }
+    // matrices the wave kernel does not cover (dense, or tables larger than LDS): the block kernel in its Newton mode
+    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
+    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
+    HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
+    const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
+    long blocks = (long)h->num_cu * per_cu;
+    if (blocks > B) blocks = B;
+    hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev,
+                       (double*)x_dev, (double*)y_dev, (double*)z_dev, (double*)nullptr, (double*)nullptr, (int*)nullptr,
+                       (int*)nullptr, qhead, (const int*)nullptr, mu, dy_dev, nrefine_dev, o);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel (Newton mode) launch");
     return 0;
 }
 
@@ -1103,6 +1165,7 @@ int pycllp_hip_sparse_max_cols(void) { return BLK_MAX_N; }
 
 void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (!h) return;
+    if (h->sp) pycllp_hip_sparse_free(h->sp);
     if (h->pack) (void)hipFree(h->pack);
     if (h->a_rm) (void)hipFree(h->a_rm);
     if (h->queue) (void)hipFree(h->queue);

@@ -328,8 +328,31 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
             self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
             self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_sparse_solve")
 
-    def newton_step(self, *a, **k):
-        raise NotImplementedError("the stand-alone Newton step is provided by the dense solver only")
+    def newton_step(self, x, z, y, b, c, mu, **options):
+        """Stand-alone Newton step dy for B states with the sparse shared A: the reference's ``sparse_solve_primal_normal``
+        kernel (``pycllp/cl/ldl.cl:656-712``) as launched by its ``tests/test_ldl.py:276-361``."""
+        if self._handle is None:
+            raise RuntimeError("newton_step() called before init()")
+        x, z, y, b, c = [self._dev(np.atleast_2d(v) if not isinstance(v, torch.Tensor) else v) for v in (x, z, y, b, c)]
+        B = int(x.shape[0])
+        dy = torch.empty((B, self.m), dtype=torch.float64, device=self.device)
+        nref = torch.empty(B, dtype=torch.int32, device=self.device)
+        opts = dict(self.options); opts.update(options)
+        o = _native.default_opts(**opts)
+        with torch.cuda.device(self.device):
+            _native.check(_native.lib().pycllp_hip_sparse_newton(
+                self._handle, B, self._ptr(x), self._ptr(z), self._ptr(y), self._ptr(b), self._ptr(c), float(mu),
+                self._ptr(dy), self._ptr(nref), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_sparse_newton")
+        torch.cuda.synchronize(self.device)
+        self.nrefine = nref.cpu().numpy()
+        return dy.cpu().numpy()
 
     def launch_info(self):
-        raise NotImplementedError("launch_info is provided by the dense solver only")
+        """grid / block / LDS bytes of the last solve and which kernel ran it: 'wave' = the register-resident
+        one-LP-per-wavefront kernel (csrc/ipm_wreg.hip), 'block' = the one-LP-per-workgroup kernel (csrc/ipm_block.inc)."""
+        vals = [ctypes.c_int() for _ in range(4)]
+        _native.check(_native.lib().pycllp_hip_sparse_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
+                      "pycllp_hip_sparse_launch_info")
+        d = dict(zip(("grid", "block", "lds_bytes", "kernel"), [v.value for v in vals]))
+        d["kernel"] = "wave" if d["kernel"] else "block"
+        return d

@@ -272,14 +272,50 @@ def test_shapes_up_to_the_maximum(m, n):
 
 
 def test_unsupported_size_raises():
-    A, b, c = problems.random_dense_arrays(33, 20, 2, seed=0)
+    A, b, c = problems.random_dense_arrays(129, 20, 2, seed=0)
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
     with pytest.raises(NotImplementedError):
         lp.init(solver_registry["hip_dense_primal_normal"]())
-    A, b, c = problems.random_dense_arrays(8, 125, 2, seed=0)
+    A, b, c = problems.random_dense_arrays(8, 510, 2, seed=0)
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
     with pytest.raises(NotImplementedError):
         lp.init(solver_registry["hip_dense_primal_normal"]())
+
+
+@pytest.mark.parametrize("m,n,B", [(100, 80, 24), (33, 20, 40), (8, 200, 40), (128, 256, 12)])
+def test_dense_solver_beyond_the_lane_group_kernels(m, n, B):
+    """The reference's dense host has no size cap (pycllp/solvers/cl.py:28-83): beyond m = 32 / N = 128 the dense plugin
+    hands the LP to the kernels of the sparse path (up to m = 128, N = 512).  Parity against the oracle as everywhere."""
+    A, b, c = problems.random_dense_arrays(m, n, B, seed=m + n)
+    elp, s = solve_arrays(A, b, c)
+    r = oracle_on(elp)
+    np.testing.assert_array_equal(s.status, r["status"])
+    assert (s.status == 0).all()
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    np.testing.assert_allclose(s.x, r["x"], rtol=1e-5, atol=1e-6)
+    elp2, s2 = solve_arrays(A, b, c, hsd=True)
+    assert (s2.status == 0).all() and rel_err(s2.primal_obj, r["pobj"]).max() < 1e-8
+
+
+def test_dense_newton_step_reference_recipe():
+    """The reference's own test of its stand-alone kernel solve_primal_normal (tests/test_ldl.py:219-273: seed 123456,
+    m = 100, n = 80 dense (+100 slack), 32 systems, mu = 1) through the DENSE plugin, against the known-answer formula of
+    tests/test_ldl.py:196-216 at the reference's tolerance (rtol 1e-5)."""
+    from oracle import port
+    m, n, cl_size = 100, 80, 32
+    np.random.seed(123456)
+    A = np.c_[np.random.rand(m, n), np.eye(m)]
+    x = np.random.rand(m + n, cl_size); z = np.random.rand(m + n, cl_size)
+    y = np.random.rand(m, cl_size); b = np.random.rand(m, cl_size)
+    c = np.r_[np.random.rand(n, cl_size), np.zeros((m, cl_size))]
+    lp = EqualityLP(SparseMatrix(matrix=A), b.T[:1], c.T[:1], 0.0)
+    s = solver_registry["hip_dense_primal_normal"]()
+    lp.init(s)
+    dy = s.newton_step(x.T, z.T, y.T, b.T, c.T, 1.0)
+    for i in range(cl_size):
+        ref = port.newton_step_known_answer(A, x[:, i], z[:, i], y[:, i], b[:, i], c[:, i], 1.0)
+        np.testing.assert_allclose(dy[i], ref, rtol=1e-5, atol=1e-5)
 
 
 def test_infeasible_and_unbounded_status_codes_match_oracle():
@@ -654,3 +690,100 @@ def test_autoscale_on_badly_scaled_lps(kind):
             lp.init(s2); lp.solve(s2)
         else:
             raise ValueError("n/a")
+
+
+# ---- register-resident wavefront-per-LP kernel of the sparse path (csrc/ipm_wreg.hip) ---------------------------------
+
+def test_sparse_wave_and_block_kernels_agree():
+    """The default (register-resident, one LP per wavefront) kernel and the workgroup-per-LP kernel (PYCLLP_FLAG_BLOCK_KERNEL)
+    are two implementations of the same semantics: same status, iterations within 1, objectives to 1e-9."""
+    from pycllp_amd import _native
+    A, b, c = problems.random_sparse_arrays(128, 256, 200, density=0.025, seed=11)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    for hsd in (False, True):
+        res = {}
+        for name, fl in (("wave", 0), ("block", _native.FLAG_BLOCK_KERNEL)):
+            s = solver_registry["hip_sparse_primal_normal"](flags=fl, hsd=hsd)
+            lp.init(s); lp.solve(s)
+            assert s.launch_info()["kernel"] == name
+            res[name] = s
+        w, k = res["wave"], res["block"]
+        np.testing.assert_array_equal(w.status, k.status)
+        assert (w.status == 0).all()
+        assert np.abs(w.iters.astype(int) - k.iters).max() <= 1
+        assert rel_err(w.primal_obj, k.primal_obj).max() < 1e-9 and rel_err(w.dual_obj, k.dual_obj).max() < 1e-9
+
+
+def test_sparse_config5_full_share_properties():
+    """BASELINE configs[4], the full per-GPU share (16 384 LPs, shared sparse A 128 x 256): size-independent properties, as
+    test_full_size_batch_properties does for configs[2] -- every LP optimal, KKT residuals, zero gap, bit-identical
+    results under a permutation of the batch."""
+    B = 16384
+    A, b, c = problems.random_sparse_arrays(128, 256, B, density=0.025, seed=0)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    for hsd in (False, True):
+        s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
+        lp.init(s)
+        st = lp.solve(s).copy()
+        assert s.launch_info()["kernel"] == "wave"
+        assert (st == 0).all()
+        x, y, z = s.x.copy(), s.y.copy(), s.z.copy()
+        po, du = s.primal_obj.copy(), s.dual_obj.copy()
+        Ae = lp.A.tocsr()
+        nb = 1.0 + np.linalg.norm(lp.b, axis=1); nc = 1.0 + np.linalg.norm(lp.c, axis=1)
+        assert (np.linalg.norm(lp.b - (Ae @ x.T).T, axis=1) / nb).max() < 1e-8          # primal feasibility
+        assert (np.linalg.norm(lp.c - (Ae.T @ y.T).T + z, axis=1) / nc).max() < 1e-8    # dual feasibility
+        assert x.min() >= 0 and z.min() >= 0
+        assert (np.abs(po - du) / np.maximum(1.0, np.abs(po))).max() < 1e-8             # zero gap
+        assert np.abs(np.einsum("ij,ij->i", lp.c, x) - po).max() < 1e-8 * np.abs(po).max()
+        assert s.iters.max() < 200 and 35 < s.iters.mean() < 60
+        perm = np.random.RandomState(1).permutation(B)                                  # batch order is immaterial
+        lp2 = StandardLP(SparseMatrix(matrix=A), b[perm], c[perm], 0.0).to_equality_form()
+        lp2.solve(s)
+        np.testing.assert_array_equal(s.primal_obj, po[perm])
+        np.testing.assert_array_equal(s.x, x[perm])
+
+
+def test_sparse_newton_step_reference_recipe():
+    """The reference's own test of its stand-alone kernel sparse_solve_primal_normal (tests/test_ldl.py:276-361: seed
+    123456, m = 100, n = 80 (+100 slack), density 0.025, 32 systems, mu = 1) against the known-answer formula of
+    tests/test_ldl.py:196-216, at the reference's tolerance."""
+    from scipy.sparse import rand
+    from oracle import port
+    m, n, cl_size = 100, 80, 32
+    np.random.seed(123456)
+    A = np.c_[rand(m, n, density=0.025).toarray(), np.eye(m)]
+    x = np.random.rand(m + n, cl_size); z = np.random.rand(m + n, cl_size)
+    y = np.random.rand(m, cl_size); b = np.random.rand(m, cl_size)
+    c = np.r_[np.random.rand(n, cl_size), np.zeros((m, cl_size))]
+    mu = 1.0
+    lp = EqualityLP(SparseMatrix(matrix=A), b.T[:1], c.T[:1], 0.0)
+    s = solver_registry["hip_sparse_primal_normal"]()
+    lp.init(s)
+    dy = s.newton_step(x.T, z.T, y.T, b.T, c.T, mu)
+    for i in range(cl_size):
+        ref = port.newton_step_known_answer(A, x[:, i], z[:, i], y[:, i], b[:, i], c[:, i], mu)
+        np.testing.assert_allclose(dy[i], ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dy[i], port.solve_primal_normal(A, x[:, i], z[:, i], y[:, i], b[:, i], c[:, i], mu), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,B", [(100, 32), (128, 5), (37, 9), (16, 3), (1, 2)])
+def test_ldl_solves_against_numpy(n, B):
+    """solve_ldl, forward_backward_ldl, forward_backward and forward_backward_modified_ldl (pycllp/ldl.py:147-281) on the
+    device against numpy.linalg.solve, as the reference's tests/test_ldl.py:119-136 do."""
+    from pycllp_amd import ldl as hip_ldl
+    A = _spd_batch(n, B, seed=n)
+    rs = np.random.RandomState(n + 1)
+    b = rs.rand(B, n)
+    ref = np.linalg.solve(A, b[..., None])[..., 0]
+    np.testing.assert_allclose(hip_ldl.solve_ldl(A, b), ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(hip_ldl.solve_ldl(A[0], b[0]), ref[0], rtol=1e-9, atol=1e-12)
+    D, L = hip_ldl.ldl(A)
+    np.testing.assert_allclose(hip_ldl.forward_backward_ldl(L, D, b), ref, rtol=1e-9, atol=1e-12)
+    C = np.linalg.cholesky(A)
+    np.testing.assert_allclose(hip_ldl.forward_backward(C, np.swapaxes(C, -1, -2), b), ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(hip_ldl.forward_backward(L * D[:, None, :], np.swapaxes(L, -1, -2), b), ref, rtol=1e-9, atol=1e-12)
+    # the guard is inactive on a positive definite matrix with a tiny delta: same answer
+    np.testing.assert_allclose(hip_ldl.forward_backward_modified_ldl(A, b, delta=1e-300), ref, rtol=1e-9, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        hip_ldl.solve_ldl(np.eye(129), np.ones(129))
