@@ -67,19 +67,38 @@ def cpu_baseline(seconds=12.0):
                       "(the C solver keeps global state: not thread-safe)" % (done, dt)}
 
 
-def cpu_port_all_cores(nlp=32768):
-    """The oracle restatement (same algorithm as the kernel, OpenMP over LPs) on every host core: the all-core figure of
-    SURVEY 8d, reported NEXT TO cpu_baseline (the reference solver itself cannot use threads)."""
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows all of the
+    host's hardware threads in the mask but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_port(ref_rate=None, nlp_single=1024, nlp_all=16384):
+    """The oracle restatement (same algorithm as the kernel) on the host: single thread, and OpenMP over LPs on every core
+    the process may use -- the all-core figure of SURVEY 8d, reported NEXT TO cpu_baseline (the reference solver itself
+    cannot use threads).  `vs_reference_1core` is the port / reference single-thread ratio SURVEY 8d asks to carry."""
     from oracle import port
     from pycllp_amd import problems
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    A, b, c = problems.random_dense_arrays(M, N_STD, nlp, seed=0)
+    cores = usable_cores()
+    A, b, c = problems.random_dense_arrays(M, N_STD, nlp_all, seed=0)
     Ae, be, ce = problems.equality_arrays(A, b, c)
+    port.dense_solve(Ae, be[:64], ce[:64], nthreads=1)
+    t = time.perf_counter(); port.dense_solve(Ae, be[:nlp_single], ce[:nlp_single], nthreads=1); d1 = time.perf_counter() - t
     port.dense_solve(Ae, be[:256], ce[:256], nthreads=cores)
     t = time.perf_counter(); r = port.dense_solve(Ae, be, ce, nthreads=cores); dt = time.perf_counter() - t
     assert (r["status"] == 0).all()
-    return {"value": nlp / dt, "unit": "LPs/s", "cores": cores, "kind": "port",
-            "sample": "first %d LPs of the workload, oracle/ipm_dense_ref.c with OpenMP on %d threads, %.1f s" % (nlp, cores, dt)}
+    one = nlp_single / d1
+    return {"value": nlp_all / dt, "unit": "LPs/s", "cores": cores, "kind": "port",
+            "single_thread": one, "vs_reference_1core": (one / ref_rate) if ref_rate else None,
+            "sample": "oracle/ipm_dense_ref.c: first %d LPs of the workload on 1 thread (%.1f s), first %d LPs with OpenMP on "
+                      "%d threads = the CPU share of this box (%.1f s)" % (nlp_single, d1, nlp_all, cores, dt)}
 
 
 def main():
@@ -116,7 +135,7 @@ def main():
     from pycllp_amd import problems
     from pycllp_amd.lp import SparseMatrix, EqualityLP
     from pycllp_amd.solvers import solver_registry
-    from pycllp_amd.dist import gather_batch
+    from pycllp_amd.dist import PackedGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +161,7 @@ def main():
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
-        cpu_all = cpu_port_all_cores()
+        cpu_all = cpu_port(cpu["value"] if cpu["kind"] == "reference" else None)
 
     B = args.batch
     sparse = args.workload == "sparse5"
@@ -180,40 +199,26 @@ def main():
     # The six result arrays of a solve are views into one packed allocation (HipDensePrimalNormalSolver._buffers), so the
     # gather is ONE collective of gather_bytes per rank per step.
     layout = solver._pack_layout(B)
-    gbytes = layout["_gather_bytes"]
-    recv = None
-    if multi and rank == 0:
-        recv = [[torch.empty(gbytes, dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
-
-    def wait_slot(sl):
-        if pending[sl] is not None:
-            for wk in pending[sl]:
-                wk.wait()
-            pending[sl] = None
+    pg = PackedGather(layout, world, rank, cdev, dst=0, slots=2) if multi else None
 
     def step(k, e0=None, e1=None):
         sl = k % 2
-        wait_slot(sl)
+        if multi:
+            pg.wait(sl)                  # slot sl (solver outputs + receive buffers) is free again
         if e0 is not None:
             e0.record()
         buf = solver.solve_device(bd, cd, slot=sl)     # the dominant kernel, on torch's current stream
         if e1 is not None:
             e1.record()
         if multi:
-            t = buf["packed"][:gbytes]
-            t = t.to(cdev) if args.rehearse else t
-            works = [dist.gather(t, recv[sl] if rank == 0 else None, dst=0, async_op=True)]
-            if args.sync_gather:
-                for wk in works:
-                    wk.wait()
-            else:
-                pending[sl] = works
+            t = buf["packed"]
+            pg.post(k, t.to(cdev) if args.rehearse else t, sync=args.sync_gather)
         return buf
 
     for k in range(args.warmup):
         step(k)
-    wait_slot(0); wait_slot(1)
+    if multi:
+        pg.wait()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def fence():
@@ -226,18 +231,15 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         buf = step(k, ev[k][0], ev[k][1])
-    wait_slot(0); wait_slot(1)
+    if multi:
+        pg.wait()
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    gathered = None
-    if multi and rank == 0:
-        last = (args.steps - 1) % 2
-        parts = [solver.unpack(r, layout, names=fields) for r in recv[last]]
-        gathered = {f: torch.cat([pt[f] for pt in parts], dim=0) for f in fields}
+    gathered = pg.results(args.steps - 1, names=fields) if multi else None
 
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
     status = buf["status"].cpu().numpy()
@@ -292,12 +294,23 @@ def main():
         else:
             f_lp = flops_per_lp(m_, Nn, iters_mean)
         tflops = f_lp * B / (kern_ms * 1e-3) / 1e12
-        gbs = bytes_per_lp(m_, Nn) * B / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        # executed work: the slack-aware dense kernel runs the Gram product and the mat-vecs on the n = N - m dense
+        # columns only (the identity columns of [A | I] bypass them); the sparse formula above already counts executed work
+        f_exec = f_lp if sparse else iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
+        tflops_exec = f_exec * B / (kern_ms * 1e-3) / 1e12
+        b_survey = 16 * (m_ + Nn) + 24                       # b, c in; x, y out; objectives; status, iters
+        b_with_z = bytes_per_lp(m_, Nn)                      # + the dual slacks z this library also returns
+        gbs = b_survey * B / (kern_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+        # passes): a profile-sourced figure, attached only when this run is the profiled configuration
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not sparse:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
-        info = solver.launch_info() if not sparse else None
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            ent = tj.get("sparse5" if sparse else "dense3")
+            if ent and ent.get("lps_per_launch") == B and world == 1:
+                traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
+        info = solver.launch_info()
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -311,20 +324,27 @@ def main():
                                     % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
                        "lps_per_gpu": B, "lps_total": B * world, "m": m_, "n": n_, "N_equality": Nn,
                        "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world, "reserve_cus": reserve,
-                       "kernel": "ipm_block_kernel (one LP per 256-thread workgroup), PYCLLP_FLAG_HSD" if sparse else
+                       "kernel": ("%s, PYCLLP_FLAG_HSD, grid %d x block %d, %d B LDS"
+                                  % ("hsd_wreg_kernel (one LP per wavefront, factor in registers)" if info["kernel"] == "wave" else
+                                     "ipm_block_kernel (one LP per 256-thread workgroup)", info["grid"], info["block"], info["lds_bytes"]))
+                                 if sparse else
                                  "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
                                  % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},
             "solved_optimal": ok_total, "mean_ipm_iterations": iters_mean, "max_rel_duality_gap_rank0": gap,
             "parity": parity,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": kern_ms, "flop_per_lp": f_lp,
-                         "note": "FP64 FMA/MFMA peak; algorithmic flops of SURVEY 8d with the measured mean "
-                                 "iteration count, refinement passes counted as 0",
+                         "frac_executed": tflops_exec / PEAK_FP64_TFLOPS, "flop_per_lp_executed": f_exec,
+                         "note": "FP64 FMA/MFMA peak.  frac: algorithmic flops of SURVEY 8d (every column of the equality "
+                                 "form priced densely; sparse workload: term-list Gram + CSR products + dense m^3/3 LDL') with "
+                                 "the measured mean iteration count, refinement passes counted as 0.  frac_executed: the "
+                                 "flops the kernel executes (dense workload: identity columns excluded)",
                          "hbm_algorithmic": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                             "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": bytes_per_lp(M, Nn)}},
+                                             "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": b_survey,
+                                             "bytes_per_lp_with_z": b_with_z}},
             "cpu_baseline": cpu,
-            "cpu_port_all_cores": cpu_all,
+            "cpu_port": cpu_all,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -6,8 +6,10 @@
  * named *_dev is a DEVICE pointer owned by the caller (the Python host passes torch tensors'
  * data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream).  No entry point
  * synchronises the host with the device except where stated; all of them are re-entrant per handle: solves
- * may be issued from several host threads and on several streams with one handle (up to 64 launches in flight;
- * the caller keeps their output buffers apart).
+ * may be issued from several host threads and on several streams with one handle (the caller keeps their output
+ * buffers apart).  A handle keeps 64 device work-queue counters; when 64 launches of one handle are still in flight
+ * the next call waits on the host for the oldest of them (the only place a solve entry may block).
+ * *_launch_info report the plan of the LAST launch on the handle.
  * Return value: 0 on success, a negative PYCLLP_E_* code for argument errors, or a positive
  * hipError_t for runtime failures (pycllp_hip_last_error() gives the text).
  *

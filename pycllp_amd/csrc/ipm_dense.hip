@@ -24,6 +24,7 @@
 // reference algorithm with the SURVEY section 8(a) picks: relative stopping tolerance, DELTA/R of the
 // OpenCL kernel, Nocedal-Wright diagonal guard, |r|-driven iterative refinement, NaN guard.
 #include "wreg.h"
+#include <mutex>
 
 // ------------------------------------------------------------------------------------------------
 // compile-time geometry
@@ -550,18 +551,58 @@ static int set_err(int code, const char* what) {
 
 static constexpr unsigned kQueueRing = 64;   // work-queue counters per handle = launches that may be in flight at once
 
+// Device work-queue heads of the persistent kernels: a ring of kQueueRing counters, one per launch in flight, so that solves
+// issued on different streams / from different host threads with one handle never share a counter.  Every slot carries an
+// event recorded behind the launch that used it; a slot is handed out again only once that launch has finished (the
+// 65th launch in flight makes its caller wait for the oldest one instead of silently sharing its counter).
+struct QueueRing {
+    int* dev = nullptr;
+    hipEvent_t ev[kQueueRing] = {};
+    bool armed[kQueueRing] = {};
+    std::atomic<unsigned> next{0};
+    std::mutex mu[kQueueRing];
+    hipError_t create() {
+        hipError_t e = hipMalloc((void**)&dev, sizeof(int) * kQueueRing);
+        for (unsigned i = 0; e == hipSuccess && i < kQueueRing; i++) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        return e;
+    }
+    void destroy() {
+        for (unsigned i = 0; i < kQueueRing; i++) if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (dev) (void)hipFree(dev);
+        dev = nullptr;
+    }
+    // zeroed counter for a launch on `st`; *slot identifies it for release()
+    hipError_t acquire(hipStream_t st, int** head, unsigned* slot) {
+        const unsigned s = next.fetch_add(1u) % kQueueRing;
+        mu[s].lock();                                   // held until release(): two threads 64 launches apart
+        if (armed[s]) {
+            hipError_t q = hipEventSynchronize(ev[s]);   // returns at once unless 64 later launches overtook this one
+            if (q != hipSuccess) { mu[s].unlock(); return q; }
+        }
+        *head = dev + s; *slot = s;
+        hipError_t e = hipMemsetAsync(dev + s, 0, sizeof(int), st);
+        if (e != hipSuccess) mu[s].unlock();
+        return e;
+    }
+    hipError_t release(unsigned s, hipStream_t st) {
+        hipError_t e = hipEventRecord(ev[s], st);
+        armed[s] = (e == hipSuccess);
+        mu[s].unlock();
+        return e;
+    }
+};
+
 struct pycllp_hip_dense {
-    int m, n, mp, np, variant;
-    double* pack;
-    double* a_rm;   // row-major copy of A [m,n] for the group kernel
-    int* queue;     // device work-queue heads of the group kernel: a ring of kQueueRing counters, one per launch in flight,
-                    // so that solves issued on different streams with the same handle do not share a counter
-    std::atomic<unsigned> qnext;
-    int variant_sl; // index into kSlackVariants when the last m columns of A are the identity, else -1
-    int grid, block, lds;
-    int num_cu;
-    int max_lds;
-    struct pycllp_hip_sparse* sp;   // LPs beyond the lane-group kernels (m <= 128, n <= 512): served by the sparse path's kernels
+    int m = 0, n = 0, mp = 0, np = 0, variant = -1;
+    double* pack = nullptr;
+    double* a_rm = nullptr;   // row-major copy of A [m,n] for the group kernel
+    QueueRing ring; // device work-queue heads of the group kernel
+    mutable std::mutex info_mu;   // guards grid/block/lds/mp/np (what launch_info reports: the LAST launch)
+    int variant_sl = -1; // index into kSlackVariants when the last m columns of A are the identity, else -1
+    int grid = 0, block = 0, lds = 0;
+    int num_cu = 0;
+    int max_lds = 0;
+    struct pycllp_hip_sparse* sp = nullptr;   // LPs beyond the lane-group kernels (m <= 128, n <= 512): served by the sparse path's kernels
 };
 
 typedef hipError_t (*solve_launch_fn)(pycllp_hip_dense*, long, const double*, const double*, double*, double*,
@@ -578,17 +619,22 @@ static int pick_wpb(const pycllp_hip_dense* h) {
     return wpb;
 }
 
+struct LaunchPlan { int grid, block, lds, mp, np; };
+
+static void publish(pycllp_hip_dense* h, const LaunchPlan& p) {
+    std::lock_guard<std::mutex> g(h->info_mu);
+    h->grid = p.grid; h->block = p.block; h->lds = p.lds; h->mp = p.mp; h->np = p.np;
+}
+
 template <int MP, int NP>
-static void plan(pycllp_hip_dense* h, long B) {
+static LaunchPlan plan(const pycllp_hip_dense* h, long B) {
     using G = Geo<MP, NP>;
     const int wpb = pick_wpb<MP, NP>(h);
     long blocks = (B + wpb - 1) / wpb;
     const long resident = (long)h->num_cu * ((size_t)h->max_lds / G::lds_bytes(wpb) >= 2 ? 2 : 1);
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
-    h->grid = (int)blocks;
-    h->block = wpb * WAVE;
-    h->lds = (int)G::lds_bytes(wpb);
+    return LaunchPlan{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
 }
 
 template <int MP, int NP>
@@ -603,12 +649,13 @@ template <int MP, int NP>
 static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
                                double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                hipStream_t st) {
-    plan<MP, NP>(h, B);
+    const LaunchPlan p = plan<MP, NP>(h, B);
     hipError_t e = hipFuncSetAttribute((const void*)ipm_solve_kernel<MP, NP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_solve_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+    hipLaunchKernelGGL((ipm_solve_kernel<MP, NP>), dim3(p.grid), dim3(p.block), p.lds, st, h->m, h->n, B,
                        h->pack, b, c, x, y, z, pobj, dobj, status, iters, o);
+    publish(h, p);
     return hipGetLastError();
 }
 
@@ -626,28 +673,30 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     const long resident = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
-    h->grid = (int)blocks; h->block = wpb * WAVE; h->lds = (int)G::lds_bytes(wpb);
-    h->mp = MP; h->np = NP;
+    const LaunchPlan p{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
     auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
     if (e != hipSuccess) return e;
-    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
-    e = hipMemsetAsync(qhead, 0, sizeof(int), st);
+    int* qhead = nullptr; unsigned slot = 0;
+    e = h->ring.acquire(st, &qhead, &slot);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+    hipLaunchKernelGGL(kernel, dim3(p.grid), dim3(p.block), p.lds, st, h->m, h->n, B,
                        h->a_rm, b, c, x, y, z, pobj, dobj, status, iters, qhead, o);
-    return hipGetLastError();
+    e = hipGetLastError();
+    hipError_t e2 = h->ring.release(slot, st);
+    publish(h, p);
+    return e != hipSuccess ? e : e2;
 }
 
 template <int MP, int NP>
 static hipError_t launch_newton(pycllp_hip_dense* h, long B, const double* x, const double* z, const double* y,
                                 const double* b, const double* c, double mu, double* dy, int* nref, DevOpts o,
                                 hipStream_t st) {
-    plan<MP, NP>(h, B);
+    const LaunchPlan p = plan<MP, NP>(h, B);
     hipError_t e = hipFuncSetAttribute((const void*)newton_kernel<MP, NP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, h->lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((newton_kernel<MP, NP>), dim3(h->grid), dim3(h->block), h->lds, st, h->m, h->n, B,
+    hipLaunchKernelGGL((newton_kernel<MP, NP>), dim3(p.grid), dim3(p.block), p.lds, st, h->m, h->n, B,
                        h->pack, x, z, y, b, c, mu, dy, nref, o);
     return hipGetLastError();
 }
@@ -700,13 +749,13 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
 
 // ---- sparse shared-A path (one LP per workgroup) ---------------------------------------------------------------
 struct pycllp_hip_sparse {
-    BlockA desc;
-    void* dev_blob;     // one allocation holding every device array of desc
-    int* queue;         // ring of kQueueRing work-queue heads (see pycllp_hip_dense)
-    std::atomic<unsigned> qnext;
-    int lds, num_cu, grid;
-    int last_wreg;      // 1 when the last solve ran on the wave kernel
-    WregPlan* wreg;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
+    BlockA desc = {};
+    void* dev_blob = nullptr;     // one allocation holding every device array of desc
+    QueueRing ring;     // work-queue heads (see pycllp_hip_dense)
+    mutable std::mutex info_mu;
+    int lds = 0, num_cu = 0, grid = 0;
+    int last_wreg = 0;      // 1 when the last solve ran on the wave kernel
+    WregPlan* wreg = nullptr;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
 };
 
 template <typename T>
@@ -777,30 +826,30 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
         if (dptr) (void)hipFree(dptr);
         if (dcol) (void)hipFree(dcol);
         if (rc != 0) return rc;
-        pycllp_hip_dense* hs = (pycllp_hip_dense*)calloc(1, sizeof(pycllp_hip_dense));
+        pycllp_hip_dense* hs = new (std::nothrow) pycllp_hip_dense();
         if (!hs) { pycllp_hip_sparse_free(sp); return set_err(PYCLLP_E_NOMEM, "pycllp_hip_dense_init: out of host memory"); }
         hs->m = m; hs->n = n; hs->variant = -1; hs->variant_sl = -1; hs->sp = sp;
         *handle = hs;
         return 0;
     }
-    pycllp_hip_dense* h = (pycllp_hip_dense*)calloc(1, sizeof(pycllp_hip_dense));
+    pycllp_hip_dense* h = new (std::nothrow) pycllp_hip_dense();
     if (!h) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_dense_init: out of host memory");
     h->m = m; h->n = n; h->variant = vi; h->mp = kVariants[vi].mp; h->np = kVariants[vi].np;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) { free(h); return set_err((int)e, "hipGetDeviceProperties"); }
+    if (e != hipSuccess) { delete h; return set_err((int)e, "hipGetDeviceProperties"); }
     h->num_cu = prop.multiProcessorCount;
     h->max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (h->max_lds > 160 * 1024) h->max_lds = 160 * 1024;
     if (h->max_lds <= 0) h->max_lds = 64 * 1024;
     e = hipMalloc((void**)&h->pack, sizeof(double) * kVariants[vi].apack);
-    if (e != hipSuccess) { free(h); return set_err((int)e, "hipMalloc(pack)"); }
+    if (e != hipSuccess) { delete h; return set_err((int)e, "hipMalloc(pack)"); }
     e = hipMalloc((void**)&h->a_rm, sizeof(double) * (size_t)m * n);
-    if (e != hipSuccess) { (void)hipFree(h->pack); free(h); return set_err((int)e, "hipMalloc(A)"); }
-    e = hipMalloc((void**)&h->queue, sizeof(int) * kQueueRing);
-    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); free(h); return set_err((int)e, "hipMalloc(queue)"); }
+    if (e != hipSuccess) { (void)hipFree(h->pack); delete h; return set_err((int)e, "hipMalloc(A)"); }
+    e = h->ring.create();
+    if (e != hipSuccess) { h->ring.destroy(); (void)hipFree(h->pack); (void)hipFree(h->a_rm); delete h; return set_err((int)e, "hipMalloc(queue)"); }
     hipStream_t st = (hipStream_t)stream;
     e = hipMemcpyAsync(h->a_rm, A_dev, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = kVariants[vi].pack(h, A_dev, st);
@@ -821,7 +870,7 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
         }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); (void)hipFree(h->queue); free(h); return set_err((int)e, "pack_A_kernel"); }
+    if (e != hipSuccess) { (void)hipFree(h->pack); (void)hipFree(h->a_rm); h->ring.destroy(); delete h; return set_err((int)e, "pack_A_kernel"); }
     *handle = h;
     return 0;
 }
@@ -886,6 +935,7 @@ int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* bloc
         if (n_pad) *n_pad = BLK_MAX_N;
         return rc;
     }
+    std::lock_guard<std::mutex> g(h->info_mu);
     if (grid) *grid = h->grid;
     if (block) *block = h->block;
     if (lds_bytes) *lds_bytes = h->lds;
@@ -969,13 +1019,13 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     }
     ent_ptr.push_back((int)terms.size());
 
-    pycllp_hip_sparse* h = (pycllp_hip_sparse*)calloc(1, sizeof(pycllp_hip_sparse));
+    pycllp_hip_sparse* h = new (std::nothrow) pycllp_hip_sparse();
     if (!h) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_sparse_init: out of host memory");
     int dev = 0;
     hipDeviceProp_t prop;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) { free(h); return set_err((int)e, "hipGetDeviceProperties"); }
+    if (e != hipSuccess) { delete h; return set_err((int)e, "hipGetDeviceProperties"); }
     h->num_cu = prop.multiProcessorCount;
     int max_lds = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (max_lds > 160 * 1024 || max_lds <= 0) max_lds = 160 * 1024;
@@ -984,8 +1034,8 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
                                         term_col.size()) + 16 * 12;
     std::vector<char> host(total);
     e = hipMalloc(&h->dev_blob, total);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->queue, sizeof(int) * kQueueRing);
-    if (e != hipSuccess) { if (h->dev_blob) (void)hipFree(h->dev_blob); free(h); return set_err((int)e, "hipMalloc(sparse A)"); }
+    if (e == hipSuccess) e = h->ring.create();
+    if (e != hipSuccess) { h->ring.destroy(); if (h->dev_blob) (void)hipFree(h->dev_blob); delete h; return set_err((int)e, "hipMalloc(sparse A)"); }
     size_t off = 0;
     char* db = (char*)h->dev_blob;
     BlockA& d = h->desc;
@@ -998,7 +1048,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     d.n_entries = (int)ent_tri.size(); d.n_terms = (int)terms.size();
     e = hipMemcpyAsync(h->dev_blob, host.data(), off, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h); return set_err((int)e, "upload sparse A"); }
+    if (e != hipSuccess) { (void)hipFree(h->dev_blob); h->ring.destroy(); delete h; return set_err((int)e, "upload sparse A"); }
     // LDS plan: two workgroups per CU hide each other's LDS latency, so the CSR/CSC copy goes into LDS only when the
     // workgroup still fits in half a CU (or when it cannot be paired anyway)
     const size_t mp8 = ((size_t)m + 7) & ~(size_t)7;
@@ -1010,7 +1060,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     else d.a_in_lds = with_a <= (size_t)max_lds ? 1 : 0;
     h->lds = (int)(d.a_in_lds ? with_a : base);
     if ((size_t)h->lds > (size_t)max_lds) {
-        (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
+        (void)hipFree(h->dev_blob); h->ring.destroy(); delete h;
         return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_init: problem does not fit in LDS");
     }
     // the register-resident one-LP-per-wavefront kernel takes over whenever its tables fit (ipm_wreg.hip)
@@ -1018,7 +1068,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
         WregPlan* wp = nullptr;
         const int rc = wreg_plan_create(m, n, nnz, val.data(), ptr.data(), col.data(), max_lds, st, &wp);
         if (rc >= 1000) {
-            (void)hipFree(h->dev_blob); (void)hipFree(h->queue); free(h);
+            (void)hipFree(h->dev_blob); h->ring.destroy(); delete h;
             return set_err(rc - 1000, "wreg_plan_create");
         }
         h->wreg = (rc == 0) ? wp : nullptr;
@@ -1038,29 +1088,41 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
-    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
-    HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     int* worklist = nullptr;
+    int grid_w = 0;
     const bool use_wreg = h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_AUTOSCALE));
-    h->last_wreg = use_wreg ? 1 : 0;
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
         HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));
-        hipError_t ew = wreg_launch_solve(h->wreg, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev,
-                                          iters_dev, qhead, worklist, o, h->num_cu, st, &h->grid);
+        int* qw = nullptr; unsigned sw = 0;
+        hipError_t ew = h->ring.acquire(st, &qw, &sw);
+        if (ew == hipSuccess) {
+            ew = wreg_launch_solve(h->wreg, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qw,
+                                   worklist, o, h->num_cu, st, &grid_w);
+            hipError_t er = h->ring.release(sw, st);
+            if (ew == hipSuccess) ew = er;
+        }
         if (ew != hipSuccess) { (void)hipFreeAsync(worklist, st); return set_err((int)ew, "ipm_wreg_kernel launch"); }
-        qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
-        HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     }
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     long blocks = free_cus * per_cu;
     if (blocks > B) blocks = B;
-    if (!use_wreg) h->grid = (int)blocks;
-    hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
-                       y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, o);
-    hipError_t e = hipGetLastError();
+    int* qhead = nullptr; unsigned slot = 0;
+    hipError_t e = h->ring.acquire(st, &qhead, &slot);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
+                           y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, o);
+        e = hipGetLastError();
+        hipError_t er = h->ring.release(slot, st);
+        if (e == hipSuccess) e = er;
+    }
     if (worklist) { hipError_t e2 = hipFreeAsync(worklist, st); if (e == hipSuccess) e = e2; }
+    {
+        std::lock_guard<std::mutex> g(h->info_mu);
+        h->last_wreg = use_wreg ? 1 : 0;
+        h->grid = use_wreg ? grid_w : (int)blocks;
+    }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
     return 0;
 }
@@ -1081,21 +1143,26 @@ int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, 
     }
     // matrices the wave kernel does not cover (dense, or tables larger than LDS): the block kernel in its Newton mode
     HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
-    int* qhead = h->queue + (h->qnext.fetch_add(1u) % kQueueRing);
-    HIP_TRY(hipMemsetAsync(qhead, 0, sizeof(int), st));
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     long blocks = (long)h->num_cu * per_cu;
     if (blocks > B) blocks = B;
-    hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev,
-                       (double*)x_dev, (double*)y_dev, (double*)z_dev, (double*)nullptr, (double*)nullptr, (int*)nullptr,
-                       (int*)nullptr, qhead, (const int*)nullptr, mu, dy_dev, nrefine_dev, o);
-    hipError_t e = hipGetLastError();
+    int* qhead = nullptr; unsigned slot = 0;
+    hipError_t e = h->ring.acquire(st, &qhead, &slot);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev,
+                           (double*)x_dev, (double*)y_dev, (double*)z_dev, (double*)nullptr, (double*)nullptr, (int*)nullptr,
+                           (int*)nullptr, qhead, (const int*)nullptr, mu, dy_dev, nrefine_dev, o);
+        e = hipGetLastError();
+        hipError_t er = h->ring.release(slot, st);
+        if (e == hipSuccess) e = er;
+    }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel (Newton mode) launch");
     return 0;
 }
 
 int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse* h, int* grid, int* block, int* lds_bytes, int* kernel) {
     if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_launch_info: bad argument");
+    std::lock_guard<std::mutex> g(h->info_mu);
     if (grid) *grid = h->grid;
     if (block) *block = BLK_T;
     if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->wreg) : h->lds;
@@ -1155,9 +1222,9 @@ int pycllp_hip_forward_backward_ldl(int n, long B, const double* L_dev, const do
 void pycllp_hip_sparse_free(pycllp_hip_sparse* h) {
     if (!h) return;
     if (h->dev_blob) (void)hipFree(h->dev_blob);
-    if (h->queue) (void)hipFree(h->queue);
+    h->ring.destroy();
     wreg_plan_free(h->wreg);
-    free(h);
+    delete h;
 }
 
 int pycllp_hip_sparse_max_rows(void) { return BLK_MAX_M; }
@@ -1168,8 +1235,8 @@ void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (h->sp) pycllp_hip_sparse_free(h->sp);
     if (h->pack) (void)hipFree(h->pack);
     if (h->a_rm) (void)hipFree(h->a_rm);
-    if (h->queue) (void)hipFree(h->queue);
-    free(h);
+    h->ring.destroy();
+    delete h;
 }
 
 }  // extern "C"

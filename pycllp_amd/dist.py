@@ -66,3 +66,56 @@ def solve_sharded(local_solve, b_local, c_local, sizes, group=None, fields=("pob
         if g is not None:
             gathered[k] = g
     return res, (gathered if gathered else None)
+
+
+class PackedGather(object):
+    """The path's one collective as ``bench.py`` and a multi-GPU caller issue it: every rank holds the results of a solve
+    in ONE packed device allocation (``pycllp_amd.solvers.hip.pack_layout``: pobj | dobj | status | iters | y | x | z), and the
+    first ``gather_bytes`` bytes of it travel to rank ``dst`` in a single ``dist.gather``.  The gather is asynchronous and
+    double-buffered: ``post(k, packed)`` uses slot ``k % slots`` -- receive buffers on ``dst`` included -- after waiting
+    for the gather that last used the slot, so the transfer of step k overlaps the solve of step k+1.
+
+    Ragged shards: build the layout for ``max(sizes)`` LPs on every rank; ``results(k)`` slices rank r's arrays to ``sizes[r]``.
+    """
+
+    def __init__(self, layout, world_size, rank, device, dst=0, group=None, slots=2, sizes=None):
+        self.layout, self.world, self.rank, self.dst, self.group, self.slots = layout, world_size, rank, dst, group, slots
+        self.nbytes = int(layout["_gather_bytes"])
+        self.sizes = list(sizes) if sizes is not None else None
+        self.recv = None
+        if rank == dst:
+            self.recv = [[torch.empty(self.nbytes, dtype=torch.uint8, device=device) for _ in range(world_size)]
+                         for _ in range(slots)]
+        self.pending = [None] * slots
+
+    def wait(self, k=None):
+        """Block until the gather of slot ``k % slots`` (all slots when ``k`` is None) has completed."""
+        for sl in (range(self.slots) if k is None else [k % self.slots]):
+            if self.pending[sl] is not None:
+                self.pending[sl].wait()
+                self.pending[sl] = None
+
+    def post(self, k, packed, sync=False):
+        """Gather the first ``gather_bytes`` bytes of ``packed`` (uint8, on the collective's device) to ``dst``."""
+        sl = k % self.slots
+        self.wait(sl)
+        if packed.dtype != torch.uint8 or packed.numel() < self.nbytes:
+            raise ValueError("packed must be a uint8 tensor of at least %d bytes" % self.nbytes)
+        work = dist.gather(packed[:self.nbytes], self.recv[sl] if self.rank == self.dst else None, dst=self.dst,
+                           group=self.group, async_op=True)
+        if sync:
+            work.wait()
+        else:
+            self.pending[sl] = work
+        return work
+
+    def results(self, k, names=("pobj", "dobj", "status", "iters", "y", "x")):
+        """On ``dst``: the gathered arrays of step ``k`` concatenated in rank order (None elsewhere).  Waits for that gather."""
+        self.wait(k)
+        if self.rank != self.dst:
+            return None
+        from .solvers.hip import unpack
+        parts = [unpack(buf, self.layout, names=names) for buf in self.recv[k % self.slots]]
+        if self.sizes is not None:
+            parts = [{f: p[f][:self.sizes[r]] for f in names} for r, p in enumerate(parts)]
+        return {f: torch.cat([p[f] for p in parts], dim=0) for f in names}

@@ -18,6 +18,36 @@ from . import BaseSolver
 from .. import _native
 
 
+# order of the result arrays inside the one allocation that holds them (HipDensePrimalNormalSolver._buffers)
+PACK_ORDER = (("pobj", torch.float64), ("dobj", torch.float64), ("status", torch.int32), ("iters", torch.int32),
+              ("y", torch.float64), ("x", torch.float64), ("z", torch.float64))
+
+
+def pack_layout(B, m, n):
+    """(offset, nbytes, dtype, shape) of every result array of a B-LP solve in its packed allocation, 256-byte aligned
+    sections; everything up to and including x -- what a result gather ships -- forms a contiguous prefix of
+    ``_gather_bytes`` bytes (``pycllp_amd.dist.PackedGather``)."""
+    shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "y": (B, m), "x": (B, n), "z": (B, n)}
+    layout, off = {}, 0
+    for name, dt in PACK_ORDER:
+        nb = int(np.prod(shapes[name], dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
+        layout[name] = (off, nb, dt, shapes[name])
+        off = (off + nb + 255) & ~255
+        if name == "x":
+            layout["_gather_bytes"] = off
+    layout["_total_bytes"] = off
+    return layout
+
+
+def unpack(packed, layout, names=("pobj", "dobj", "status", "iters", "y", "x")):
+    """Views of the result arrays inside a packed byte buffer (e.g. one received from another rank)."""
+    out = {}
+    for name in names:
+        off, nb, dt, shape = layout[name]
+        out[name] = packed[off:off + nb].view(dt).view(shape)
+    return out
+
+
 def _require_gpu(device):
     if not torch.cuda.is_available():
         raise RuntimeError("pycllp_amd: no ROCm device visible -- the HIP solvers have no CPU fallback")
@@ -96,33 +126,12 @@ class HipDensePrimalNormalSolver(BaseSolver):
         self.m, self.n = m, n
         self.buffers = {}
 
-    # order of the result arrays inside the one allocation that holds them (see _buffers)
-    _PACK_ORDER = (("pobj", torch.float64), ("dobj", torch.float64), ("status", torch.int32), ("iters", torch.int32),
-                   ("y", torch.float64), ("x", torch.float64), ("z", torch.float64))
-
     def _pack_layout(self, B):
-        """(offset, nbytes, dtype, shape) of every result array in the packed allocation, 256-byte aligned sections;
-        everything up to and including x -- what a result gather ships -- forms a contiguous prefix."""
-        shapes = {"pobj": (B,), "dobj": (B,), "status": (B,), "iters": (B,), "y": (B, self.m), "x": (B, self.n),
-                  "z": (B, self.n)}
-        layout, off = {}, 0
-        for name, dt in self._PACK_ORDER:
-            nb = int(np.prod(shapes[name], dtype=np.int64)) * torch.empty((), dtype=dt).element_size()
-            layout[name] = (off, nb, dt, shapes[name])
-            off = (off + nb + 255) & ~255
-            if name == "x":
-                layout["_gather_bytes"] = off
-        layout["_total_bytes"] = off
-        return layout
+        return pack_layout(B, self.m, self.n)
 
     @staticmethod
     def unpack(packed, layout, names=("pobj", "dobj", "status", "iters", "y", "x")):
-        """Views of the result arrays inside a packed byte buffer (e.g. one received from another rank)."""
-        out = {}
-        for name in names:
-            off, nb, dt, shape = layout[name]
-            out[name] = packed[off:off + nb].view(dt).view(shape)
-        return out
+        return unpack(packed, layout, names)
 
     def _buffers(self, B, slot=0):
         """Output tensors of one solve: views into ONE device allocation (``packed``, bytes), so that a caller who ships
@@ -135,7 +144,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
             layout = self._pack_layout(B)
             packed = torch.empty(max(layout["_total_bytes"], 256), dtype=torch.uint8, device=self.device)
             cur = dict(B=B, packed=packed, layout=layout, gather_bytes=layout["_gather_bytes"])
-            cur.update(self.unpack(packed, layout, names=[n for n, _ in self._PACK_ORDER]))
+            cur.update(self.unpack(packed, layout, names=[n for n, _ in PACK_ORDER]))
             self.buffers[key] = cur
         return cur
 
