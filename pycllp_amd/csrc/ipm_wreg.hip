@@ -65,7 +65,7 @@ constexpr int STAGE_D = HB * 256;
 constexpr int TILE_OFF = 512, RR_OFF = 800;   // aliases inside the stage (free once the blocks are in registers)
 constexpr int WL = 128;          // doubles reserved per packed W block (120 used: strictly lower triangle, row i at i(i-1)/2)
 constexpr int MAX_NQ = 8;
-constexpr int META_SEG = MAX_NQ, META_DSEG = META_SEG + 24, META_N = META_DSEG + 24;
+constexpr int META_COFF = MAX_NQ, META_SEG = 2 * MAX_NQ, META_DSEG = META_SEG + 24, META_N = META_DSEG + 24;
 
 template <int MB>
 struct WGeo {
@@ -86,15 +86,17 @@ struct WGeo {
 struct WregTab {
     int m, n, nnz;
     int rmax, n_ent, n_term;
-    int meta[META_N];     // [0..8) deepest column of column register q, [META_SEG..) first Gram entry of staging chunk i
-                          // (chunks in (K, ch) order; NCHUNK + 1 used), [META_DSEG..) first Gram entry of diagonal block
-                          // K (MB + 1 used) -- copied to LDS
+    int meta[META_N];     // [0..8) ELL depth of column register q, [META_COFF..) its first ELL slot, [META_SEG..) first Gram
+                          // entry of staging chunk i (chunks in (K, ch) order; NCHUNK + 1 used), [META_DSEG..) first Gram
+                          // entry of diagonal block K (MB + 1 used) -- copied to LDS
     const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
-    const double* csc_val; const unsigned short* csc_row; const unsigned short* csc_ptr; const unsigned short* csc_len;
+    // A by columns in ELL form over column POSITIONS: the columns are dealt to the (lane, register) positions of the
+    // N-vectors sorted by length, so that each register's 64 columns are about equally long (JDS); colmap[pos] = column
+    const double* ec_val; const unsigned short* ec_row; const unsigned short* colmap; int ctot;
     const unsigned* e_ptr; const unsigned short* e_dst;   // Gram entries: term range, offset inside the stage / tile
     const double* t_w; const unsigned short* t_col;       // Gram terms: a_ij a_kj and the column j
-    int o_csr_val, o_csc_val, o_t_w, o_wave, o_e_ptr, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_csc_row, o_csc_ptr,
-        o_csc_len, o_e_dst, o_t_col;                      // LDS byte offsets
+    int o_csr_val, o_ec_val, o_t_w, o_wave, o_e_ptr, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
+        o_e_dst, o_t_col;                                 // LDS byte offsets
     int wave_doubles, lds_bytes;
 };
 
@@ -154,7 +156,7 @@ struct WReg {
     PBlk P[G::NBLK > 0 ? G::NBLK : 1];
     // LDS: shared tables (A by rows and by columns in compact form, Gram entries/terms)
     const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
-    const double* csc_val; const unsigned short* csc_row; const unsigned short* csc_ptr; const unsigned short* csc_len;
+    const double* ec_val; const unsigned short* ec_row; const unsigned short* colmap;
     const unsigned* e_ptr; const unsigned short* e_dst;
     const double* t_w; const unsigned short* t_col;
     const int* meta;
@@ -173,27 +175,21 @@ struct WReg {
     __device__ __forceinline__ double* wl_() const { return W0 + STAGE_D + NP + 6 * MP; }       // [MB][WL] W_K = L_KK^-1, strict lower triangle packed by rows
     int lane, q, c16, m, n, rmax;
 
-    // out_q = (A'u)_j for the columns j = lane + 64 q of this lane, u in LDS.  The NQ column registers advance together
-    // (t outer, q inner): NQ independent gather chains in flight instead of one.
+    // out_q = (A'u)_j for the column at position lane + 64 q (see colmap), u in LDS.  ELL: slot t of register q sits at
+    // (coff_q + t) 64 + lane -- an immediate offset from one lane-dependent base; padded slots hold value 0, row 0.
     __device__ __forceinline__ void At(const double* u, double (&out)[NQ]) const {
-        int ptr[NQ], len[NQ];
-        int cm = 0;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            ptr[qq] = csc_ptr[lane + 64 * qq]; len[qq] = csc_len[lane + 64 * qq];
-            out[qq] = 0.0;
-            cm = max(cm, __builtin_amdgcn_readfirstlane(meta[qq]));
-        }
-#pragma unroll 2
-        for (int t = 0; t < cm; t++) {
-#pragma unroll
-            for (int qq = 0; qq < NQ; qq++) {
-                const bool on = t < len[qq];
-                const int p = on ? ptr[qq] + t : 0;
-                const double a = csc_val[p];
-                const double uv = u[csc_row[p]];
-                out[qq] = fma(on ? a : 0.0, uv, out[qq]);
+            const int cm = __builtin_amdgcn_readfirstlane(meta[qq]);
+            const int base = __builtin_amdgcn_readfirstlane(meta[META_COFF + qq]) * 64 + lane;
+            double a0 = 0.0, a1 = 0.0;
+            int t = 0;
+            for (; t + 1 < cm; t += 2) {
+                a0 = fma(ec_val[base + 64 * t], u[ec_row[base + 64 * t]], a0);
+                a1 = fma(ec_val[base + 64 * t + 64], u[ec_row[base + 64 * t + 64]], a1);
             }
+            if (t < cm) a0 = fma(ec_val[base + 64 * t], u[ec_row[base + 64 * t]], a0);
+            out[qq] = a0 + a1;
         }
     }
     // (A v)_i for the rows i = lane + 64 r2 of this lane, v staged in LDS; with DIAG also diag(A diag(d) A')_i (d in vd_();
@@ -224,12 +220,35 @@ struct WReg {
         }
     }
 
-    // value of Gram entry e: sum over its terms of a_ij a_kj d_j
-    __device__ __forceinline__ double entry_value(int e) const {
-        const unsigned p1 = e_ptr[e + 1];
-        double acc = 0.0;
-        for (unsigned p = e_ptr[e]; p < p1; p++) acc = fma(t_w[p], vd_()[t_col[p]], acc);
-        return acc;
+    // dstbuf[e_dst[e]] (+)= value of Gram entry e (sum over its terms of a_ij a_kj d_j) for the entries [e0, e1): FOUR
+    // entries per lane per trip with every table read of the trip issued before the first use (one wavefront alone on its
+    // SIMD hides no latency by itself); the first term of an entry -- for most entries the only one -- is on that fast
+    // path, further terms in a short tail loop
+    template <bool ADD>
+    __device__ __forceinline__ void scatter_entries(double* dstbuf, int e0, int e1) const {
+        const double* vdp = vd_();
+        for (int e = e0 + lane; e < e1; e += 256) {
+            unsigned p0[4], p1[4];
+            int dst[4];
+            bool on[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                on[k] = e + 64 * k < e1;
+                const int ek = on[k] ? e + 64 * k : e0;
+                p0[k] = e_ptr[ek]; p1[k] = e_ptr[ek + 1]; dst[k] = e_dst[ek];
+            }
+            double wv[4]; int cj[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { wv[k] = t_w[p0[k]]; cj[k] = t_col[p0[k]]; }
+            double acc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc[k] = wv[k] * vdp[cj[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                for (unsigned p = p0[k] + 1; p < p1[k]; p++) acc[k] = fma(t_w[p], vdp[t_col[p]], acc[k]);
+                if (on[k]) { if (ADD) dstbuf[dst[k]] += acc[k]; else dstbuf[dst[k]] = acc[k]; }
+            }
+        }
     }
 
     // Off-diagonal blocks of M = A diag(d) A' (d in vd_()) -> U, one staging chunk of <= HB blocks at a time.  The diagonal
@@ -246,13 +265,8 @@ struct WReg {
 #pragma unroll
                 for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage_())[w * 64 + lane] = zero;
                 wave_lds_sync();
-                const int e1 = __builtin_amdgcn_readfirstlane(meta[META_SEG + ci + 1]);
-                int e = __builtin_amdgcn_readfirstlane(meta[META_SEG + ci]) + lane;
-                for (; e + 64 < e1; e += 128) {          // two entries per lane per trip: two independent chains
-                    const double v0 = entry_value(e), v1 = entry_value(e + 64);
-                    stage_()[e_dst[e]] = v0; stage_()[e_dst[e + 64]] = v1;
-                }
-                if (e < e1) stage_()[e_dst[e]] = entry_value(e);
+                scatter_entries<false>(stage_(), __builtin_amdgcn_readfirstlane(meta[META_SEG + ci]),
+                                       __builtin_amdgcn_readfirstlane(meta[META_SEG + ci + 1]));
                 wave_lds_sync();
 #pragma unroll
                 for (int bi = 0; bi < nb; bi++) {
@@ -269,17 +283,17 @@ struct WReg {
     // tile += diagonal block K of M = A diag(d) A' (strict lower triangle from the entry tables, the diagonal from Md)
     template <int K>
     __device__ __forceinline__ void diag_from_tables(double* tile, const double (&Md)[MR]) const {
-        const int e1 = __builtin_amdgcn_readfirstlane(meta[META_DSEG + K + 1]);
-        for (int e = __builtin_amdgcn_readfirstlane(meta[META_DSEG + K]) + lane; e < e1; e += 64) tile[e_dst[e]] += entry_value(e);
+        scatter_entries<true>(tile, __builtin_amdgcn_readfirstlane(meta[META_DSEG + K]),
+                              __builtin_amdgcn_readfirstlane(meta[META_DSEG + K + 1]));
         if (q == (K & 3)) tile[c16 * 18] += Md[K >> 2];   // row 16K + c16 lives in lane 16(K&3) + c16 of register K>>2
     }
 
-    // W_K element [row c16][column 4s + q] from the packed copy in LDS
+    // W_K element [row 4s + q][column c16] -- the TRANSPOSED operand layout -- from the packed copy in LDS
     template <int K>
-    __device__ __forceinline__ double w_elem(int s) const {
-        const int col = 4 * s + q;
-        const double v = wl_()[K * WL + ((col < c16) ? c16 * (c16 - 1) / 2 + col : 0)];
-        return (col < c16) ? v : ((col == c16) ? 1.0 : 0.0);
+    __device__ __forceinline__ double w_elemT(int s) const {
+        const int row = 4 * s + q;
+        const double v = wl_()[K * WL + ((c16 < row) ? row * (row - 1) / 2 + c16 : 0)];
+        return (c16 < row) ? v : ((c16 == row) ? 1.0 : 0.0);
     }
 
     // Blocked LDL' of the matrix whose off-diagonal blocks are in U; `diag_add(Kc, tile)` adds the original diagonal
@@ -311,6 +325,7 @@ struct WReg {
             STAMP(2)
             diag_add(Kc, tile);
             wave_lds_sync();
+            STAMP(3)
             double Wd[16], Ld[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
@@ -340,7 +355,7 @@ struct WReg {
                 asm volatile("" : "+v"(rDr[j >> 2]), "+v"(aDr[j >> 2]), "+v"(rdiag), "+v"(adiag), "+v"(viol));
             });
             if (q == 0) { rdv_()[16 * K + c16] = rdiag; adv_()[16 * K + c16] = adiag; }
-            STAMP(3)
+            STAMP(4)
             // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q]; packed copy to LDS ----
             double Ws[4];
 #pragma unroll
@@ -354,7 +369,6 @@ struct WReg {
             });
 #pragma unroll
             for (int s = 0; s < 4; s++) if (4 * s + q < c16) wl_()[K * WL + c16 * (c16 - 1) / 2 + 4 * s + q] = Ws[s];
-            STAMP(4)
             // ---- panel: Y_KI = W M_KI = D_K L_IK' on the matrix cores.  The block stays UNSCALED in its accumulator
             //      registers (every use below is an MFMA operand or folds 1/D into a vector): nothing ever writes a
             //      resident block from the VALU side.  Guard test: Y^2 > beta^2 D. ----
@@ -398,30 +412,31 @@ struct WReg {
         return __any(viol != 0);
     }
 
-    // um_() <- (L D L')^-1 um_().  Forward substitution is column oriented (t_K, once known, is folded into the partial sums of
-    // all later block rows and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
+    // um <- (L D L')^-1 um.  Vectors of a 16-row block appear in two forms: "column form" (lane (c16, q) holds element
+    // c16, identical in the four quads) and "row form" (register r of lane (c16, q) holds element 4r + q, identical in the
+    // 16 lanes of a quad).  With W_K read in the TRANSPOSED operand layout (element [4s+q][c16]) every product maps one
+    // form onto the other with a DPP row reduction or a quad reduction and NO layout conversion through LDS:
+    //   forward   t_I = W_I r_I:   r column form -> products -> row_sum  -> t in row form  (what the Y blocks multiply)
+    //   backward  x_K = W_K' v_K:  v row form    -> products -> quad_sum -> x in column form (what the Y blocks multiply)
+    // Forward substitution is column oriented (t_K, once known, is folded into the partial sums of all later block rows
+    // and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
     __device__ __forceinline__ void solve() {
-        double* rr = stage_() + RR_OFF;
         double p[MB];
 #pragma unroll
         for (int I = 0; I < MB; I++) p[I] = 0.0;
-        // forward: t_I = W_I (s_I - sum_{K<I} L_IK t_K)
+        // forward: t_I = W_I (s_I - sum_{K<I} L_IK t_K), L_IK t_K = Y_KI' (D_K^-1 t_K)
         static_for<0, MB>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
             double rC = um_()[16 * I + c16];
             if constexpr (I > 0) rC -= quad_sum(p[I]);
-            if (q == 0) rr[c16] = rC;
-            wave_lds_sync();
-            double pt = 0.0;
+            double tR[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) pt = fma(w_elem<I>(s), rr[4 * s + q], pt);
-            const double tC = quad_sum(pt);
-            if (q == 0) um_()[16 * I + c16] = tC;
-            wave_lds_sync();
+            for (int s = 0; s < 4; s++) tR[s] = row_sum(w_elemT<I>(s) * rC);
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (c16 == 0) um_()[16 * I + 4 * s + q] = tR[s];
             if constexpr (I + 1 < MB) {
-                double tR[4];      // D_I^-1 t_I: the resident blocks are Y = D L'
 #pragma unroll
-                for (int r = 0; r < 4; r++) tR[r] = um_()[16 * I + 4 * r + q] * rdv_()[16 * I + 4 * r + q];
+                for (int r = 0; r < 4; r++) tR[r] *= rdv_()[16 * I + 4 * r + q];     // D_I^-1 t_I: the resident blocks are Y = D L'
                 static_for<I + 1, MB>([&](auto Jc) {
                     constexpr int J = decltype(Jc)::value;
 #pragma unroll
@@ -429,6 +444,7 @@ struct WReg {
                 });
             }
         });
+        wave_lds_sync();
         // backward: x_K = W_K' D_K^-1 (t_K - sum_{I>K} Y_KI x_I)
         double xCL[MB];
         static_for<0, MB>([&](auto Kr) {
@@ -439,24 +455,18 @@ struct WReg {
 #pragma unroll
                 for (int r = 0; r < 4; r++) pr[r] = fma(unpark(P[G::bix(K, I)], r), xCL[I], pr[r]);
             });
+            double px = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 double v = um_()[16 * K + 4 * r + q];
                 if constexpr (K < MB - 1) v -= row_sum(pr[r]);
-                v *= rdv_()[16 * K + 4 * r + q];
-                if (c16 == 0) rr[4 * r + q] = v;
+                px = fma(w_elemT<K>(r), v * rdv_()[16 * K + 4 * r + q], px);
             }
-            wave_lds_sync();
-            const double rC = rr[c16];
-            double xs[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) xs[s] = row_sum(w_elem<K>(s) * rC);
-            wave_lds_sync();
-#pragma unroll
-            for (int s = 0; s < 4; s++) if (c16 == 0) um_()[16 * K + 4 * s + q] = xs[s];
-            wave_lds_sync();
-            xCL[K] = um_()[16 * K + c16];
+            xCL[K] = quad_sum(px);
         });
+        wave_lds_sync();
+#pragma unroll
+        for (int K = 0; K < MB; K++) if (q == 0) um_()[16 * K + c16] = xCL[K];
         wave_lds_sync();
     }
 };
@@ -472,31 +482,31 @@ template <int MB, int NQ>
 __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, unsigned char* lraw, int tid) {
     using G = WGeo<MB>;
     double* s_csr_val = (double*)(lraw + T.o_csr_val);
-    double* s_csc_val = (double*)(lraw + T.o_csc_val);
+    double* s_ec_val = (double*)(lraw + T.o_ec_val);
     double* s_t_w = (double*)(lraw + T.o_t_w);
     unsigned* s_e_ptr = (unsigned*)(lraw + T.o_e_ptr);
     int* s_meta = (int*)(lraw + T.o_meta);
     unsigned short* s_csr_col = (unsigned short*)(lraw + T.o_csr_col);
     unsigned short* s_csr_ptr = (unsigned short*)(lraw + T.o_csr_ptr);
     unsigned short* s_csr_len = (unsigned short*)(lraw + T.o_csr_len);
-    unsigned short* s_csc_row = (unsigned short*)(lraw + T.o_csc_row);
-    unsigned short* s_csc_ptr = (unsigned short*)(lraw + T.o_csc_ptr);
-    unsigned short* s_csc_len = (unsigned short*)(lraw + T.o_csc_len);
+    unsigned short* s_ec_row = (unsigned short*)(lraw + T.o_ec_row);
+    unsigned short* s_colmap = (unsigned short*)(lraw + T.o_colmap);
     unsigned short* s_e_dst = (unsigned short*)(lraw + T.o_e_dst);
     unsigned short* s_t_col = (unsigned short*)(lraw + T.o_t_col);
     const int nth = blockDim.x;
     for (int i = tid; i < T.nnz; i += nth) {
-        s_csr_val[i] = T.csr_val[i]; s_csr_col[i] = T.csr_col[i]; s_csc_val[i] = T.csc_val[i]; s_csc_row[i] = T.csc_row[i];
+        s_csr_val[i] = T.csr_val[i]; s_csr_col[i] = T.csr_col[i];
     }
     for (int i = tid; i < G::MPL; i += nth) { s_csr_ptr[i] = T.csr_ptr[i]; s_csr_len[i] = T.csr_len[i]; }
-    for (int i = tid; i < 64 * NQ; i += nth) { s_csc_ptr[i] = T.csc_ptr[i]; s_csc_len[i] = T.csc_len[i]; }
+    for (int i = tid; i < T.ctot * 64; i += nth) { s_ec_val[i] = T.ec_val[i]; s_ec_row[i] = T.ec_row[i]; }
+    for (int i = tid; i < 64 * NQ; i += nth) s_colmap[i] = T.colmap[i];
     for (int i = tid; i < T.n_term; i += nth) { s_t_w[i] = T.t_w[i]; s_t_col[i] = T.t_col[i]; }
     for (int i = tid; i < T.n_ent; i += nth) s_e_dst[i] = T.e_dst[i];
     for (int i = tid; i <= T.n_ent; i += nth) s_e_ptr[i] = T.e_ptr[i];
     for (int i = tid; i < META_N; i += nth) s_meta[i] = T.meta[i];
     __syncthreads();
     w.csr_val = s_csr_val; w.csr_col = s_csr_col; w.csr_ptr = s_csr_ptr; w.csr_len = s_csr_len;
-    w.csc_val = s_csc_val; w.csc_row = s_csc_row; w.csc_ptr = s_csc_ptr; w.csc_len = s_csc_len;
+    w.ec_val = s_ec_val; w.ec_row = s_ec_row; w.colmap = s_colmap;
     w.e_ptr = s_e_ptr; w.e_dst = s_e_dst; w.t_w = s_t_w; w.t_col = s_t_col; w.meta = s_meta;
     wreg_carve(w, (double*)(lraw + T.o_wave) + (size_t)(tid >> 6) * T.wave_doubles, tid);
     w.m = T.m; w.n = T.n; w.rmax = T.rmax;
@@ -588,8 +598,9 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     const double nm = (double)(n + m);
     double* vx = w.stage_();
     bool okc[NQ], okr[MR];
+    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
+    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
 
@@ -605,7 +616,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         double c2 = 0.0;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = lane + 64 * qq;
+            const int j = jc[qq];
             const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
             c2 = fma(cj, cj, c2);
             x[qq] = (warm && okc[qq]) ? xg[lp * n + j] : 1.0;
@@ -633,11 +644,12 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         while (running) {
             // ---- sigma, gamma, objectives (primal_normal.cl:96-120, 245-248) ----
             double v[NQ], cq[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) cq[qq] = okc[qq] ? cg[lp * n + jc[qq]] : 0.0;   // in flight (vmcnt) while A'y runs on LDS
             w.At(w.ys_(), v);
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                cq[qq] = okc[qq] ? cg[lp * n + lane + 64 * qq] : 0.0;
                 const double sg = okc[qq] ? cq[qq] - v[qq] + z[qq] : 0.0;
                 s2 = fma(sg, sg, s2);
                 gam += okc[qq] ? x[qq] * z[qq] : 0.0;
@@ -743,7 +755,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         } else {
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                const int j = lane + 64 * qq;
+                const int j = jc[qq];
                 if (okc[qq]) { xg[lp * n + j] = x[qq]; if (zg) zg[lp * n + j] = z[qq]; }
             }
 #pragma unroll
@@ -790,8 +802,9 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     double* vx = w.stage_();
     double* pv = w.flr_();          // p = M^-1 (A(d c) - b): the floor vector is dead once the factor exists
     bool okc[NQ], okr[MR];
+    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
+    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
 
@@ -807,7 +820,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         double c2 = 0.0, g0 = 0.0;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = lane + 64 * qq;
+            const int j = jc[qq];
             const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
             c2 = fma(cj, cj, c2);
             x[qq] = (warm && okc[qq]) ? xg[lp * n + j] : 1.0;
@@ -837,11 +850,12 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         while (running) {
             // ---- sigma = c tau - A'y + z, gamma, objectives ----
             double v[NQ], cq[NQ], sg[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) cq[qq] = okc[qq] ? cg[lp * n + jc[qq]] : 0.0;   // in flight (vmcnt) while A'y runs on LDS
             w.At(w.ys_(), v);
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                cq[qq] = okc[qq] ? cg[lp * n + lane + 64 * qq] : 0.0;
                 sg[qq] = okc[qq] ? cq[qq] * tau - v[qq] + z[qq] : 0.0;
                 s2 = fma(sg[qq], sg[qq], s2);
                 gam += okc[qq] ? x[qq] * z[qq] : 0.0;
@@ -1043,7 +1057,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             const double rt = (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT) ? 1.0 / tau : 1.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                const int j = lane + 64 * qq;
+                const int j = jc[qq];
                 if (okc[qq]) { xg[lp * n + j] = x[qq] * rt; if (zg) zg[lp * n + j] = z[qq] * rt; }
             }
 #pragma unroll
@@ -1084,8 +1098,9 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
     const int lane = w.lane, m = w.m, n = w.n;
     double* vx = w.stage_();
     bool okc[NQ], okr[MR];
+    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
+    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
     long lp;
@@ -1109,10 +1124,10 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
         w.At(w.ys_(), v);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = lane + 64 * qq;
-            x[qq] = okc[qq] ? xg[lp * n + j] : 1.0;
-            z[qq] = okc[qq] ? zg[lp * n + j] : 1.0;
-            const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
+            const int j = lane + 64 * qq, jg = jc[qq];
+            x[qq] = okc[qq] ? xg[lp * n + jg] : 1.0;
+            z[qq] = okc[qq] ? zg[lp * n + jg] : 1.0;
+            const double cj = okc[qq] ? cg[lp * n + jg] : 0.0;
             t[qq] = okc[qq] ? cj - v[qq] + mu * fast_rcp(x[qq]) : 0.0;
             vx[j] = okc[qq] ? x[qq] : 0.0;
             w.vd_()[j] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
@@ -1314,17 +1329,10 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     WregTab& T = P->tab;
     memset(&T, 0, sizeof(T));
     T.m = m; T.n = n; T.nnz = nnz;
-    // ---- A by rows (as given) and by columns ----
-    std::vector<double> csr_val(val, val + nnz), csc_val(nnz);
-    std::vector<unsigned short> csr_col(nnz), csc_row(nnz), csr_ptr(MPL, 0), csr_len(MPL, 0), csc_ptr(NP, 0), csc_len(NP, 0);
-    int rmax = 0;
-    for (int i = 0; i < m; i++) {
-        csr_ptr[i] = (unsigned short)ptr[i]; csr_len[i] = (unsigned short)(ptr[i + 1] - ptr[i]);
-        rmax = std::max(rmax, ptr[i + 1] - ptr[i]);
-    }
-    for (int e = 0; e < nnz; e++) csr_col[e] = (unsigned short)col[e];
-    T.rmax = rmax;
+    // ---- column positions: the columns sorted by length (longest first) are dealt to positions 0, 1, ...; position p
+    //      is element p % 64 of N-vector register p / 64, so every register holds 64 columns of similar length ----
     std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<double> csc_val(nnz);
     for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
     for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
     {
@@ -1332,10 +1340,37 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
         for (int i = 0; i < m; i++)
             for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; csc_val[p] = val[e]; }
     }
-    for (int e = 0; e < nnz; e++) csc_row[e] = (unsigned short)crow[e];
-    for (int j = 0; j < n; j++) {
-        csc_ptr[j] = (unsigned short)cptr[j]; csc_len[j] = (unsigned short)(cptr[j + 1] - cptr[j]);
-        T.meta[j / 64] = std::max(T.meta[j / 64], cptr[j + 1] - cptr[j]);
+    std::vector<int> order(n), posof(n);
+    for (int j = 0; j < n; j++) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cptr[a + 1] - cptr[a] > cptr[b + 1] - cptr[b]; });
+    std::vector<unsigned short> colmap(NP, 0);
+    for (int p = 0; p < n; p++) { colmap[p] = (unsigned short)order[p]; posof[order[p]] = p; }
+    // ---- A by rows (column indices = positions), compact ----
+    std::vector<double> csr_val(val, val + nnz);
+    std::vector<unsigned short> csr_col(nnz), csr_ptr(MPL, 0), csr_len(MPL, 0);
+    int rmax = 0;
+    for (int i = 0; i < m; i++) {
+        csr_ptr[i] = (unsigned short)ptr[i]; csr_len[i] = (unsigned short)(ptr[i + 1] - ptr[i]);
+        rmax = std::max(rmax, ptr[i + 1] - ptr[i]);
+    }
+    for (int e = 0; e < nnz; e++) csr_col[e] = (unsigned short)posof[col[e]];
+    T.rmax = rmax;
+    // ---- A by columns, ELL over positions ----
+    int ctot = 0;
+    for (int q = 0; q < NQ; q++) {
+        int cm = 0;
+        for (int p = 64 * q; p < std::min(n, 64 * q + 64); p++) cm = std::max(cm, cptr[order[p] + 1] - cptr[order[p]]);
+        T.meta[q] = cm; T.meta[META_COFF + q] = ctot; ctot += cm;
+    }
+    T.ctot = ctot;
+    std::vector<double> ec_val((size_t)std::max(ctot, 1) * 64, 0.0);
+    std::vector<unsigned short> ec_row((size_t)std::max(ctot, 1) * 64, 0);
+    for (int p = 0; p < n; p++) {
+        const int j = order[p], q = p / 64, l = p % 64;
+        for (int e = cptr[j], t = 0; e < cptr[j + 1]; e++, t++) {
+            ec_val[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = csc_val[e];
+            ec_row[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = (unsigned short)crow[e];
+        }
     }
     // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk, then the entries
     //      inside the diagonal blocks grouped by block ----
@@ -1351,10 +1386,10 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
                 const int i = crow[a], k = crow[b2];   // rows ascend inside a column: i > k
                 const int K = k / 16, I = i / 16;
                 if (I == K) {          // diagonal block K: element [i%16][k%16] of the stride-17 tile
-                    terms.push_back({nchunk + K, (i % 16) * 17 + (k % 16), j, csc_val[a] * csc_val[b2]});
+                    terms.push_back({nchunk + K, (i % 16) * 17 + (k % 16), posof[j], csc_val[a] * csc_val[b2]});
                 } else {               // block (K, I) of U: element [k%16][i%16], block (I-K-1) % HB of its chunk
                     const int ch = (I - K - 1) / HB, bi = (I - K - 1) % HB;
-                    terms.push_back({chbase[K] + ch, bi * 256 + (k % 16) * 16 + (i % 16), j, csc_val[a] * csc_val[b2]});
+                    terms.push_back({chbase[K] + ch, bi * 256 + (k % 16) * 16 + (i % 16), posof[j], csc_val[a] * csc_val[b2]});
                 }
                 if (terms.size() > ((size_t)1 << 22)) { delete P; return 1; }
             }
@@ -1382,7 +1417,7 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 15) & ~(size_t)15; const size_t o_ = off; off += bytes; return (int)o_; };
     T.o_csr_val = take(sizeof(double) * csr_val.size());
-    T.o_csc_val = take(sizeof(double) * csc_val.size());
+    T.o_ec_val = take(sizeof(double) * ec_val.size());
     T.o_t_w = take(sizeof(double) * t_w.size());
     T.wave_doubles = STAGE_D + 64 * NQ + 6 * MP + MB * WL;
     T.o_wave = take(sizeof(double) * 4 * (size_t)T.wave_doubles);
@@ -1391,28 +1426,27 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     T.o_csr_col = take(sizeof(unsigned short) * csr_col.size());
     T.o_csr_ptr = take(sizeof(unsigned short) * csr_ptr.size());
     T.o_csr_len = take(sizeof(unsigned short) * csr_len.size());
-    T.o_csc_row = take(sizeof(unsigned short) * csc_row.size());
-    T.o_csc_ptr = take(sizeof(unsigned short) * csc_ptr.size());
-    T.o_csc_len = take(sizeof(unsigned short) * csc_len.size());
+    T.o_ec_row = take(sizeof(unsigned short) * ec_row.size());
+    T.o_colmap = take(sizeof(unsigned short) * colmap.size());
     T.o_e_dst = take(sizeof(unsigned short) * e_dst.size());
     T.o_t_col = take(sizeof(unsigned short) * t_col.size());
     T.lds_bytes = (int)((off + 15) & ~(size_t)15);
     if (T.lds_bytes > max_lds) { delete P; return 1; }
     // ---- device copies ----
     std::vector<char> host;
-    const size_t a1 = put(host, csr_val), a2 = put(host, csc_val), a3 = put(host, t_w), a4 = put(host, e_ptr),
-                 a5 = put(host, csr_col), a6 = put(host, csr_ptr), a7 = put(host, csr_len), a8 = put(host, csc_row),
-                 a9 = put(host, csc_ptr), a10 = put(host, csc_len), a11 = put(host, e_dst), a12 = put(host, t_col);
+    const size_t a1 = put(host, csr_val), a2 = put(host, ec_val), a3 = put(host, t_w), a4 = put(host, e_ptr),
+                 a5 = put(host, csr_col), a6 = put(host, csr_ptr), a7 = put(host, csr_len), a8 = put(host, ec_row),
+                 a9 = put(host, colmap), a11 = put(host, e_dst), a12 = put(host, t_col);
     hipError_t e = hipMalloc(&P->dev_blob, host.size());
     if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { if (P->dev_blob) (void)hipFree(P->dev_blob); delete P; return 1000 + (int)e; }
     char* db = (char*)P->dev_blob;
-    T.csr_val = (const double*)(db + a1); T.csc_val = (const double*)(db + a2); T.t_w = (const double*)(db + a3);
+    T.csr_val = (const double*)(db + a1); T.ec_val = (const double*)(db + a2); T.t_w = (const double*)(db + a3);
     T.e_ptr = (const unsigned*)(db + a4);
     T.csr_col = (const unsigned short*)(db + a5); T.csr_ptr = (const unsigned short*)(db + a6);
-    T.csr_len = (const unsigned short*)(db + a7); T.csc_row = (const unsigned short*)(db + a8);
-    T.csc_ptr = (const unsigned short*)(db + a9); T.csc_len = (const unsigned short*)(db + a10);
+    T.csr_len = (const unsigned short*)(db + a7); T.ec_row = (const unsigned short*)(db + a8);
+    T.colmap = (const unsigned short*)(db + a9);
     T.e_dst = (const unsigned short*)(db + a11); T.t_col = (const unsigned short*)(db + a12);
     P->mb = MB; P->nq = NQ;
     *out = P;

@@ -1,0 +1,10 @@
+#!/bin/bash
+# diagnostic build with in-kernel phase stamps: proflib/libpycllp_hip_prof.so (use with PYCLLP_HIP_LIB=...)
+set -e
+cd /root/repo
+mkdir -p proflib
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DPYCLLP_PROFILE -c -o /tmp/wreg_prof.o pycllp_amd/csrc/ipm_wreg.hip &
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DPYCLLP_PROFILE $PROF_EXTRA -c -o /tmp/dense_prof.o pycllp_amd/csrc/ipm_dense.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o proflib/libpycllp_hip_prof.so /tmp/dense_prof.o /tmp/wreg_prof.o
+ls -la proflib/

@@ -8,12 +8,12 @@ from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry
 NPHASE = 10
 names = ["0 A'y, norms, d, t, A x, tests, A(dt), diag(M)", "1 Gram scatter + block loads", "2 LDL': Schur MFMA of the diagonal block -> tile",
-         "3 LDL': tile -> rows, 16-step pivot chain", "4 LDL': W = L_KK^-1", "5 LDL': panel (MFMA + scaling)", "6 LDL': trailing update (MFMA)",
+         "3 LDL': original diagonal block from the tables -> tile", "4 LDL': tile -> rows, 16-step pivot chain", "5 LDL': W = L_KK^-1, panel (MFMA)", "6 LDL': trailing update (MFMA)",
          "7 block substitution (solve)", "8 A'dy, dx, A dx, refinement test", "9 step, load/store LP"]
 m, n, B = 128, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 A, b, c = problems.random_sparse_arrays(m, n, B, density=0.025, seed=0)
 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
-s = solver_registry["hip_sparse_primal_normal"](); lp.init(s)
+s = solver_registry["hip_sparse_primal_normal"](hsd=bool(int(os.environ.get("HSD", "0")))); lp.init(s)
 L = _native.lib()
 prof = torch.zeros(1024 * NPHASE, dtype=torch.int64, device="cuda")
 L.pycllp_hip_debug_set_prof.argtypes = [ctypes.c_void_p]
