@@ -28,6 +28,17 @@ class BaseSolver(MetaSolver("_BaseSolver", (object,), {"name": None})):
         raise NotImplementedError()
 
 
+class BaseCSCSolver(BaseSolver):
+    """Mirror of ``pycllp/solvers/__init__.py:24-26``: ``init`` caches the compressed-sparse-column arrays of ``lp.A``."""
+
+    def init(self, lp, verbose=0):
+        self.A, self.Ai, self.Ak = lp.A.tocsc_arrays()
+
+
+class BaseGeneralSolver(BaseSolver):
+    pass
+
+
 def register_with_pycllp():
     """Insert this package's solvers into a real ``pycllp.solvers.solver_registry`` if importable."""
     try:

@@ -59,18 +59,35 @@ class HipDensePrimalNormalSolver(BaseSolver):
     (callers use ``StandardLP.to_equality_form()`` first, as for the OpenCL solver)."""
     name = 'hip_dense_primal_normal'
 
-    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale=False, hsd=False, **options):
+    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale=False, hsd="auto", warm_start=False,
+                 **options):
         """``hsd=True`` (PYCLLP_FLAG_HSD) solves on the homogeneous self-dual embedding, the model of the reference's
         CPU solver ``pycllp/ipo/hsd.c``: infeasible (status 2) and unbounded (status 4) LPs are then detected reliably,
-        after ~12-15 iterations, and ``x`` / ``y, z`` hold the certificate.
+        after ~12-15 iterations, and ``x`` / ``y, z`` hold the certificate.  ``hsd="auto"`` (default) runs the reference's
+        own path (``pycllp/cl/primal_normal.cl:201-284``) and then re-solves, on the embedding, exactly those LPs that did
+        not end optimal: an optimal LP gets the drop-in behaviour, every other one a verdict with a certificate instead of
+        the outcome of the reference kernel's 10x-growth heuristic (which labels most infeasible LPs "iteration limit").
+        ``hsd=False`` is the reference's path alone.
+        ``warm_start=True``: repeat solve -- the library's stated purpose (reference ``README.md:5-6``, the intent recorded
+        at ``pycllp/cl/primal_normal.cl:213-219``): the solver keeps x, z, y of the previous ``solve()`` on the device and
+        starts every LP that was optimal there from its previous point (PYCLLP_FLAG_WARM_START); the others, and a first
+        solve or one with a different batch size, start from x = z = y = 1.
         ``autoscale=True`` (PYCLLP_FLAG_AUTOSCALE, not in the reference) solves every LP with b/max|b| and c/max|c| and
         scales the results back: use it when b or c are orders of magnitude away from 1.  Other keyword arguments are
         the fields of ``pycllp_hip_opts`` (eps, delta, r, pivot_floor, refine_tol, max_iter, max_refine, flags)."""
         super(HipDensePrimalNormalSolver, self).__init__()
+        if hsd not in (True, False, "auto"):
+            raise ValueError("hsd must be True, False or 'auto'")
         if autoscale:
             options["flags"] = int(options.get("flags", 0)) | _native.FLAG_AUTOSCALE
-        if hsd:
+        if hsd is True or (int(options.get("flags", 0)) & _native.FLAG_HSD):
             options["flags"] = int(options.get("flags", 0)) | _native.FLAG_HSD
+            hsd = True
+        if int(options.get("flags", 0)) & _native.FLAG_WAVE_KERNEL and hsd == "auto":
+            hsd = False          # the first-generation kernel has no embedding
+        self.hsd = hsd
+        self.warm_start = bool(warm_start)
+        self._prev_B = None
         self.device = device
         self.stream = stream
         self.keep_on_device = keep_on_device
@@ -197,7 +214,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
             self.buffers["host"] = st
         return st
 
-    def _solve_host(self, b, c):
+    def _solve_host(self, b, c, warm=False):
         """numpy in, numpy out, as a three-stage pipeline over row chunks of the batch: upload chunk k+1, solve
         chunk k and download chunk k-1 run on three HIP streams, so the PCIe time hides behind the kernel.  The
         returned arrays are views of the solver's page-locked buffers and are overwritten by the next solve()
@@ -208,7 +225,10 @@ class HipDensePrimalNormalSolver(BaseSolver):
                              % (self.m, self.n, tuple(b.shape), tuple(c.shape)))
         B = int(b.shape[0])
         st, buf = self._host_staging(B), self._buffers(B, 0)
-        o = _native.default_opts(**self.options)
+        opts = dict(self.options)
+        if warm:
+            opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
+        o = _native.default_opts(**opts)
         if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
             raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
         nchunk = max(1, min(self.PIPELINE_CHUNKS, B // self.PIPELINE_MIN_BATCH))
@@ -235,6 +255,39 @@ class HipDensePrimalNormalSolver(BaseSolver):
             st["s_out"].synchronize()
         return {k: st[k].numpy() for k in outs}
 
+    def _prepare_warm(self, B):
+        """True when this solve may start from the previous solution: same batch size, a previous solve exists.  LPs that
+        did not end optimal last time are reset to the cold start x = z = y = 1 (their x, z may hold a certificate)."""
+        if not self.warm_start or self._prev_B != B or "set0" not in self.buffers:
+            return False
+        buf = self.buffers["set0"]
+        bad = buf["status"] != 0
+        if bool(bad.any()):
+            buf["x"][bad] = 1.0; buf["z"][bad] = 1.0; buf["y"][bad] = 0.0 if self.hsd is True else 1.0
+        return True
+
+    def _resolve_non_optimal(self, b, c, res):
+        """hsd='auto': the LPs that did not end optimal are solved again on the homogeneous self-dual embedding and their
+        results replace the first verdict.  ``res``: dict of numpy arrays or CUDA tensors of the first solve."""
+        status = res["status"]
+        idx = torch.nonzero(status != 0).flatten() if isinstance(status, torch.Tensor) else np.flatnonzero(status != 0)
+        if len(idx) == 0:
+            return
+        if isinstance(b, torch.Tensor) or isinstance(c, torch.Tensor):
+            it = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
+            b2, c2 = self._dev(b)[it], self._dev(c)[it]
+        else:
+            hi = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
+            b2, c2 = np.asarray(b)[hi], np.asarray(c)[hi]
+        flags = (int(self.options.get("flags", 0)) | _native.FLAG_HSD) & ~_native.FLAG_WARM_START
+        r2 = self.solve_device(b2, c2, slot=3, flags=flags)
+        torch.cuda.synchronize(self.device)
+        for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
+            if isinstance(res[k], torch.Tensor):
+                res[k][idx.to(res[k].device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=res[k].device)] = r2[k]
+            else:
+                res[k][idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx] = r2[k].cpu().numpy()
+
     def solve(self, lp, verbose=0):
         """Solve every problem of ``lp`` (current ``lp.b``, ``lp.c``); results in attributes."""
         if int(lp.nrows) != self.m or int(lp.ncols) != self.n:
@@ -244,26 +297,34 @@ class HipDensePrimalNormalSolver(BaseSolver):
         if verbose > 0:
             print("Solving %d LPs with %s..." % (lp.nproblems, type(self).__name__))
         f = np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)
+        B = int(lp.nproblems)
+        warm = self._prepare_warm(B)
         on_host = not isinstance(lp.b, torch.Tensor) and not isinstance(lp.c, torch.Tensor)
         if on_host and not self.keep_on_device:
-            res = self._solve_host(lp.b, lp.c)
+            res = self._solve_host(lp.b, lp.c, warm)
+            if self.hsd == "auto":
+                self._resolve_non_optimal(lp.b, lp.c, res)
             self.x, self.y, self.z = res["x"], res["y"], res["z"]
             self.status, self.iters = res["status"], res["iters"]
             # objective offset f is added when reporting (as pycllp/solvers/pathfollowing.py:113-114)
             self.primal_obj, self.dual_obj = res["pobj"] + f, res["dobj"] + f
         else:
-            buf = self.solve_device(lp.b, lp.c)
+            buf = self.solve_device(lp.b, lp.c, warm_start=warm)
             torch.cuda.synchronize(self.device)
+            res = {k: buf[k] for k in ("x", "y", "z", "pobj", "dobj", "status", "iters")}
+            if self.hsd == "auto":
+                self._resolve_non_optimal(lp.b, lp.c, res)
             if self.keep_on_device:
-                self.x, self.y, self.z = buf["x"], buf["y"], buf["z"]
-                self.status, self.iters = buf["status"], buf["iters"]
+                self.x, self.y, self.z = res["x"], res["y"], res["z"]
+                self.status, self.iters = res["status"], res["iters"]
                 ft = torch.as_tensor(np.broadcast_to(f, (buf["B"],)).copy(), device=self.device)
-                self.primal_obj, self.dual_obj = buf["pobj"] + ft, buf["dobj"] + ft
+                self.primal_obj, self.dual_obj = res["pobj"] + ft, res["dobj"] + ft
             else:
-                self.x = buf["x"].cpu().numpy(); self.y = buf["y"].cpu().numpy(); self.z = buf["z"].cpu().numpy()
-                self.status = buf["status"].cpu().numpy(); self.iters = buf["iters"].cpu().numpy()
-                self.primal_obj = buf["pobj"].cpu().numpy() + f
-                self.dual_obj = buf["dobj"].cpu().numpy() + f
+                self.x = res["x"].cpu().numpy(); self.y = res["y"].cpu().numpy(); self.z = res["z"].cpu().numpy()
+                self.status = res["status"].cpu().numpy(); self.iters = res["iters"].cpu().numpy()
+                self.primal_obj = res["pobj"].cpu().numpy() + f
+                self.dual_obj = res["dobj"].cpu().numpy() + f
+        self._prev_B = B
         if verbose > 0:
             print("Solve complete.")
         return self.status
