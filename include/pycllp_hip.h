@@ -162,6 +162,15 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double *Adata_dev, const
 int pycllp_hip_sparse_solve(pycllp_hip_sparse *handle, long B, const double *b_dev, const double *c_dev,
                             double *x_dev, double *y_dev, double *z_dev, double *pobj_dev, double *dobj_dev,
                             int *status_dev, int *iters_dev, const pycllp_hip_opts *opts, void *stream);
+/* The same solve with PER-PROBLEM VALUES of A on the shared structure -- SparseMatrix.data[nproblems, nnz] of the
+ * reference's container (pycllp/lp.py:16-54, 274-281), which its LP classes still refuse (lp.py:335-336).
+ * Adata_dev [B, nnz]: the values of LP k in the CSR order of the arrays given to pycllp_hip_sparse_init (whose values
+ * only fixed the structure).  One LP per workgroup; its values travel HBM -> LDS once per LP (8 nnz bytes, next to the
+ * 16 (m + n) + 24 of b, c, x, y). */
+int pycllp_hip_sparse_solve_batch(pycllp_hip_sparse *handle, long B, const double *Adata_dev, const double *b_dev,
+                                  const double *c_dev, double *x_dev, double *y_dev, double *z_dev, double *pobj_dev,
+                                  double *dobj_dev, int *status_dev, int *iters_dev, const pycllp_hip_opts *opts,
+                                  void *stream);
 /* One Newton step of the primal normal equations for B independent states with the sparse shared A: the reference's
  * stand-alone kernel sparse_solve_primal_normal (pycllp/cl/ldl.cl:656-712) as launched by its tests/test_ldl.py:276-361.
  * Arguments as pycllp_hip_dense_newton. */

@@ -18,7 +18,7 @@ EXPORTS = (
     "pycllp_hip_dense_free", "pycllp_hip_ldl",
     "pycllp_hip_sparse_max_rows", "pycllp_hip_sparse_max_cols", "pycllp_hip_sparse_init", "pycllp_hip_sparse_solve",
     "pycllp_hip_sparse_free", "pycllp_hip_sparse_newton", "pycllp_hip_sparse_launch_info",
-    "pycllp_hip_ldl_solve", "pycllp_hip_forward_backward_ldl",
+    "pycllp_hip_ldl_solve", "pycllp_hip_forward_backward_ldl", "pycllp_hip_sparse_solve_batch",
 )
 
 STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIBLE, STATUS_ITERATION_LIMIT = 0, 2, 3, 4, 5
@@ -81,6 +81,8 @@ def lib():
     L.pycllp_hip_ldl_solve.restype = ctypes.c_int
     L.pycllp_hip_forward_backward_ldl.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, dp, vp]
     L.pycllp_hip_forward_backward_ldl.restype = ctypes.c_int
+    L.pycllp_hip_sparse_solve_batch.argtypes = [vp, ctypes.c_long, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, ctypes.POINTER(Opts), vp]
+    L.pycllp_hip_sparse_solve_batch.restype = ctypes.c_int
     L.pycllp_hip_sparse_free.argtypes = [vp]
     L.pycllp_hip_sparse_free.restype = None
     L.pycllp_hip_dense_free.argtypes = [vp]

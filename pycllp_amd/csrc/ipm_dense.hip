@@ -754,6 +754,7 @@ struct pycllp_hip_sparse {
     QueueRing ring;     // work-queue heads (see pycllp_hip_dense)
     mutable std::mutex info_mu;
     int lds = 0, num_cu = 0, grid = 0;
+    int lds_with_a = 0;     // LDS bytes with A's arrays in LDS (what per-problem values need), 0 when that does not fit
     int last_wreg = 0;      // 1 when the last solve ran on the wave kernel
     WregPlan* wreg = nullptr;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
 };
@@ -987,35 +988,35 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     for (int i = 0; i < m; i++) if (ptr[i + 1] < ptr[i]) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: malformed CSR row pointer");
     for (int e = 0; e < nnz; e++) if (col[e] < 0 || col[e] >= n) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: column index out of range");
     // CSC by counting sort (rows ascending inside a column)
-    std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<int> cptr(n + 1, 0), crow(nnz), csrc(nnz);
     std::vector<double> cval(nnz);
     for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
     for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
     {
         std::vector<int> fill(cptr.begin(), cptr.end() - 1);
         for (int i = 0; i < m; i++)
-            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int q = fill[col[e]]++; crow[q] = i; cval[q] = val[e]; }
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int q = fill[col[e]]++; crow[q] = i; cval[q] = val[e]; csrc[q] = e; }
     }
     // Gram term list: entry (i,k), i >= k, gets a term a_ij a_kj for every column j holding both rows
-    struct Term { int key, colj; double w; };
+    struct Term { int key, colj; double w; int ia, ib; };
     std::vector<Term> terms;
     for (int j = 0; j < n; j++)
         for (int a = cptr[j]; a < cptr[j + 1]; a++)
             for (int b2 = cptr[j]; b2 <= a; b2++) {
                 const int i = crow[a], k = crow[b2];
                 const int hi = i > k ? i : k, lo = i > k ? k : i;
-                terms.push_back({hi * (hi + 1) / 2 + lo, j, cval[a] * cval[b2]});
+                terms.push_back({hi * (hi + 1) / 2 + lo, j, cval[a] * cval[b2], csrc[a], csrc[b2]});
                 if (terms.size() > (size_t)8 << 20) {
                     snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_init: A is too dense for the term-list Gram assembly");
                     return PYCLLP_E_UNSUPPORTED;
                 }
             }
     std::stable_sort(terms.begin(), terms.end(), [](const Term& x, const Term& y) { return x.key < y.key; });
-    std::vector<int> ent_tri, ent_ptr, term_col(terms.size());
+    std::vector<int> ent_tri, ent_ptr, term_col(terms.size()), term_ia(terms.size()), term_ib(terms.size());
     std::vector<double> term_w(terms.size());
     for (size_t t = 0; t < terms.size(); t++) {
         if (t == 0 || terms[t].key != terms[t - 1].key) { ent_tri.push_back(terms[t].key); ent_ptr.push_back((int)t); }
-        term_col[t] = terms[t].colj; term_w[t] = terms[t].w;
+        term_col[t] = terms[t].colj; term_w[t] = terms[t].w; term_ia[t] = terms[t].ia; term_ib[t] = terms[t].ib;
     }
     ent_ptr.push_back((int)terms.size());
 
@@ -1031,7 +1032,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     if (max_lds > 160 * 1024 || max_lds <= 0) max_lds = 160 * 1024;
     const size_t total = 64 + sizeof(double) * (val.size() + cval.size() + term_w.size()) +
                          sizeof(int) * (ptr.size() + col.size() + cptr.size() + crow.size() + ent_tri.size() + ent_ptr.size() +
-                                        term_col.size()) + 16 * 12;
+                                        term_col.size() + csrc.size() + term_ia.size() + term_ib.size()) + 16 * 16;
     std::vector<char> host(total);
     e = hipMalloc(&h->dev_blob, total);
     if (e == hipSuccess) e = h->ring.create();
@@ -1045,6 +1046,8 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     d.csc_ptr = blob_put(host.data(), off, cptr, db);  d.csc_row = blob_put(host.data(), off, crow, db);
     d.ent_tri = blob_put(host.data(), off, ent_tri, db); d.ent_ptr = blob_put(host.data(), off, ent_ptr, db);
     d.term_w = blob_put(host.data(), off, term_w, db);   d.term_col = blob_put(host.data(), off, term_col, db);
+    d.csc_src = blob_put(host.data(), off, csrc, db);
+    d.term_ia = blob_put(host.data(), off, term_ia, db); d.term_ib = blob_put(host.data(), off, term_ib, db);
     d.n_entries = (int)ent_tri.size(); d.n_terms = (int)terms.size();
     e = hipMemcpyAsync(h->dev_blob, host.data(), off, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1059,6 +1062,7 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     else if (base <= half) d.a_in_lds = 0;
     else d.a_in_lds = with_a <= (size_t)max_lds ? 1 : 0;
     h->lds = (int)(d.a_in_lds ? with_a : base);
+    h->lds_with_a = with_a <= (size_t)max_lds ? (int)with_a : 0;
     if ((size_t)h->lds > (size_t)max_lds) {
         (void)hipFree(h->dev_blob); h->ring.destroy(); delete h;
         return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_init: problem does not fit in LDS");
@@ -1077,9 +1081,9 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     return 0;
 }
 
-int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, const double* c_dev, double* x_dev,
-                            double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
-                            int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
+static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch, const double* b_dev, const double* c_dev,
+                             double* x_dev, double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
+                             int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
     if (!h || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: bad argument");
     if (B == 0) return 0;
     if (!b_dev || !c_dev || !x_dev || !status_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: bad argument");
@@ -1087,10 +1091,14 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
     int* worklist = nullptr;
     int grid_w = 0;
-    const bool use_wreg = h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_AUTOSCALE));
+    if (a_batch && !h->lds_with_a)
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values need A's arrays in LDS, and this A does not fit");
+    BlockA desc = h->desc;
+    int lds = h->lds;
+    if (a_batch) { desc.a_in_lds = 1; lds = h->lds_with_a; }
+    const bool use_wreg = !a_batch && h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_AUTOSCALE));
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
         HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));
@@ -1104,15 +1112,16 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
         }
         if (ew != hipSuccess) { (void)hipFreeAsync(worklist, st); return set_err((int)ew, "ipm_wreg_kernel launch"); }
     }
-    const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
+    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const long per_cu = (160 * 1024) / lds >= 4 ? 4 : ((160 * 1024) / lds >= 2 ? 2 : 1);
     const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     long blocks = free_cus * per_cu;
     if (blocks > B) blocks = B;
     int* qhead = nullptr; unsigned slot = 0;
     hipError_t e = h->ring.acquire(st, &qhead, &slot);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev, x_dev,
-                           y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, o);
+        hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), lds, st, desc, B, b_dev, c_dev, x_dev,
+                           y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, a_batch, o);
         e = hipGetLastError();
         hipError_t er = h->ring.release(slot, st);
         if (e == hipSuccess) e = er;
@@ -1125,6 +1134,19 @@ int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, c
     }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
     return 0;
+}
+
+int pycllp_hip_sparse_solve(pycllp_hip_sparse* h, long B, const double* b_dev, const double* c_dev, double* x_dev,
+                            double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
+                            int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
+    return sparse_solve_impl(h, B, nullptr, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, opts, stream);
+}
+
+int pycllp_hip_sparse_solve_batch(pycllp_hip_sparse* h, long B, const double* Adata_dev, const double* b_dev,
+                                  const double* c_dev, double* x_dev, double* y_dev, double* z_dev, double* pobj_dev,
+                                  double* dobj_dev, int* status_dev, int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
+    if (B > 0 && !Adata_dev) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve_batch: bad argument");
+    return sparse_solve_impl(h, B, Adata_dev, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, opts, stream);
 }
 
 int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, const double* z_dev, const double* y_dev,
@@ -1151,7 +1173,7 @@ int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, 
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), h->lds, st, h->desc, B, b_dev, c_dev,
                            (double*)x_dev, (double*)y_dev, (double*)z_dev, (double*)nullptr, (double*)nullptr, (int*)nullptr,
-                           (int*)nullptr, qhead, (const int*)nullptr, mu, dy_dev, nrefine_dev, o);
+                           (int*)nullptr, qhead, (const int*)nullptr, mu, dy_dev, nrefine_dev, (const double*)nullptr, o);
         e = hipGetLastError();
         hipError_t er = h->ring.release(slot, st);
         if (e == hipSuccess) e = er;

@@ -16,8 +16,10 @@ import scipy.sparse as sp
 class SparseMatrix(object):
     """One shared sparsity pattern in coordinate form (``pycllp/lp.py:16-54``).
 
-    ``data`` is ``[nproblems, nnz]``; only a single set of values (``nproblems == 1``) is accepted by
-    the LP classes, as in the reference (``pycllp/lp.py:335-336``)."""
+    ``data`` is ``[nproblems, nnz]``: one shared structure, per-problem values (``pycllp/lp.py:16-24``).  The reference's LP
+    classes accept a single set of values only (``pycllp/lp.py:335-336``: "can only have a single problem in the current
+    implementation"); here ``nproblems`` sets of values are accepted when there is one per problem of the LP, and the HIP
+    solvers read them per LP."""
 
     def __init__(self, rows=None, cols=None, data=None, matrix=None):
         if matrix is not None:
@@ -102,13 +104,13 @@ class EqualityLP(object):
             raise ValueError("If A matrix is provided then b, c and f must also be provided.")
         if not isinstance(A, SparseMatrix):
             A = SparseMatrix(matrix=A)
-        if A.nproblems > 1:
-            raise ValueError("A matrix can only have a single problem in the current implementation.")
         self.A = A
         self.b = np.array(b, dtype=np.float64)
         if self.b.ndim == 1:
             self.b = self.b.reshape(1, -1)
         nprb = self.b.shape[0]
+        if A.nproblems > 1 and A.nproblems != nprb:
+            raise ValueError("A matrix holds %d sets of values for %d problems: one shared set or one per problem." % (A.nproblems, nprb))
         self.c = np.array(c, dtype=np.float64)
         if self.c.ndim == 1:
             self.c = np.tile(self.c, (nprb, 1))
@@ -142,7 +144,68 @@ class StandardLP(EqualityLP):
 
     def to_equality_form(self):
         """Copy and append one unit slack column (objective 0) per row (``pycllp/lp.py:551-567``)."""
-        lp = EqualityLP(SparseMatrix(matrix=self.A.tocoo()), self.b.copy(), self.c.copy(), self.f.copy())
+        A = SparseMatrix(self.A._rows.copy(), self.A._cols.copy(), self.A.data.copy())   # per-problem values survive
+        A._shape = (self.nrows, self.ncols)
+        lp = EqualityLP(A, self.b.copy(), self.c.copy(), self.f.copy())
         for row in range(self.nrows):
             lp.add_col([row], [1.0], 0.0)
         return lp
+
+
+class GeneralLP(StandardLP):
+    """optimise c'x + f  subject to  a <= A x <= b,  l <= x <= u   (``pycllp/lp.py:570-623``; ``a`` defaults to "no lower
+    bound on the rows", ``l`` to 0, ``u`` to +inf; 1-D bounds are repeated for every problem)."""
+
+    def __init__(self, A=None, b=None, c=None, a=None, l=None, u=None, f=None):
+        super(GeneralLP, self).__init__(A=A, b=b, c=c, f=f)
+        if A is None:
+            self.a = np.zeros((1, 0)); self.l = np.zeros((1, 0)); self.u = np.zeros((1, 0))
+            return
+        nprb = self.nproblems
+
+        def rows_of(v, like, default):
+            if v is None:
+                return np.full(like.shape, default)
+            v = np.array(v, dtype=np.float64)
+            return np.tile(v, (nprb, 1)) if v.ndim == 1 else v
+
+        self.a = rows_of(a, self.b, -np.inf)      # the reference stores +inf and drops the row again (lp.py:597-599, 511-529)
+        self.l = rows_of(l, self.c, 0.0)
+        self.u = rows_of(u, self.c, np.inf)
+
+    def to_standard_form(self):
+        """The StandardLP  max c'x + f', A' x <= b', x >= 0  with the same optimum (``pycllp/lp.py:725-792``):
+        shift x <- x - l, write a <= A x as -A x <= -a, add x <= u - l for the finite upper bounds, and drop every row
+        without a finite bound (``remove_unbounded``, ``pycllp/lp.py:511-529``).  A row, or an upper bound, is kept when it
+        is finite for ANY problem of the batch; a problem for which it is infinite gets the bound +1e30 there."""
+        if np.isneginf(self.l).any():
+            raise ValueError('Lower bounds (l) contains -inf.')
+        m, n, B = self.nrows, self.ncols, self.nproblems
+        b, a, c, f = self.b.copy(), self.a.copy(), self.c.copy(), self.f.copy()
+        l = self.l
+        u = self.u - np.where(np.isfinite(self.u), l, 0.0)
+        for k in range(B):
+            Ak = self.A.tocsr(k if self.A.nproblems > 1 else 0)
+            Al = Ak @ l[k]
+            b[k] -= Al; a[k] -= Al
+            f[k] += c[k] @ l[k]
+        keep_lo = np.isfinite(a).any(axis=0)          # rows  -A x <= -a
+        keep_hi = np.isfinite(b).any(axis=0)          # rows   A x <=  b
+        keep_ub = np.isfinite(u).any(axis=0)          # rows     x <=  u - l
+        rows, cols, data = [], [], []
+        rhs = []
+        r0 = 0
+        for sign, keep, bound in ((-1.0, keep_lo, -a), (1.0, keep_hi, b)):
+            newrow = np.cumsum(keep) - 1 + r0
+            sel = keep[self.A._rows]
+            rows.append(newrow[self.A._rows[sel]]); cols.append(self.A._cols[sel]); data.append(sign * self.A.data[:, sel])
+            rhs.append(bound[:, keep])
+            r0 += int(keep.sum())
+        ub = np.flatnonzero(keep_ub)
+        rows.append(r0 + np.arange(ub.size)); cols.append(ub); data.append(np.ones((self.A.data.shape[0], ub.size)))
+        rhs.append(u[:, ub])
+        bb = np.concatenate(rhs, axis=1)
+        bb = np.where(np.isfinite(bb), bb, 1e30)
+        A2 = SparseMatrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(data, axis=1))
+        A2._shape = (bb.shape[1], n)
+        return StandardLP(A2, bb, c, f)

@@ -95,6 +95,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
         _native.default_opts(**self.options) if options else None  # validate names early
         self._handle = None
         self.buffers = {}
+        self._a_row0 = None
 
     # -- helpers ---------------------------------------------------------------------------------
     def _stream_ptr(self):
@@ -121,11 +122,33 @@ class HipDensePrimalNormalSolver(BaseSolver):
         except Exception:
             pass
 
+    @staticmethod
+    def consume(lp):
+        """Everything a HIP host reads from an LP object -- the reference's ``EqualityLP`` or this package's -- as plain
+        numpy: the attribute surface of ``pycllp/solvers/cl.py:35-39,99,102`` (``nrows, ncols, nproblems, A.todense(), b, c``)
+        plus ``f``.  tools/check_reference_boundary.py runs this on reference-built objects."""
+        m, n = int(lp.nrows), int(lp.ncols)
+        A = lp.A.todense() if hasattr(lp.A, "todense") else lp.A
+        A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        if A.shape != (m, n):
+            raise ValueError("A has shape %r, expected (%d, %d)" % (A.shape, m, n))
+        return dict(m=m, n=n, nproblems=int(lp.nproblems), A=A,
+                    b=np.ascontiguousarray(np.asarray(lp.b, dtype=np.float64)), c=np.ascontiguousarray(np.asarray(lp.c, dtype=np.float64)),
+                    f=np.atleast_1d(np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)))
+
     # -- plugin API ------------------------------------------------------------------------------
     def init(self, lp, verbose=0):
         """Densify and upload A once (``pycllp/solvers/cl.py:39,46``)."""
         self.device = _require_gpu(self.device)
         L = _native.lib()
+        self._delegate = None
+        if type(self) is HipDensePrimalNormalSolver and getattr(lp.A, "nproblems", 1) > 1:
+            # per-problem values of A: served by the sparse path's per-problem kernel (one LP per workgroup, values from HBM)
+            d = HipSparsePrimalNormalSolver(device=self.device, stream=self.stream, keep_on_device=self.keep_on_device,
+                                            hsd=self.hsd, warm_start=self.warm_start, **self.options)
+            d.init(lp, verbose=verbose)
+            self._delegate, self.m, self.n = d, d.m, d.n
+            return
         m, n = int(lp.nrows), int(lp.ncols)
         A = lp.A.todense() if hasattr(lp.A, "todense") else lp.A
         A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
@@ -246,7 +269,9 @@ class HipDensePrimalNormalSolver(BaseSolver):
                     up = st["s_in"].record_event()
                 compute.wait_event(up)
                 part = {k: buf[k][lo:hi] for k in outs}
+                self._a_row0 = lo          # (per-problem A values of the sparse solver: rows of this chunk)
                 self._launch(hi - lo, st["db"][lo:hi], st["dc"][lo:hi], part, o)
+                self._a_row0 = None
                 done = compute.record_event()
                 with torch.cuda.stream(st["s_out"]):
                     st["s_out"].wait_event(done)
@@ -280,8 +305,16 @@ class HipDensePrimalNormalSolver(BaseSolver):
             hi = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
             b2, c2 = np.asarray(b)[hi], np.asarray(c)[hi]
         flags = (int(self.options.get("flags", 0)) | _native.FLAG_HSD) & ~_native.FLAG_WARM_START
-        r2 = self.solve_device(b2, c2, slot=3, flags=flags)
-        torch.cuda.synchronize(self.device)
+        full_values = getattr(self, "_a_values", None)
+        if full_values is not None:      # per-problem A values (sparse solver): the rows of the LPs being re-solved
+            it2 = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
+            self._a_values = full_values[it2].contiguous()
+        try:
+            r2 = self.solve_device(b2, c2, slot=3, flags=flags)
+            torch.cuda.synchronize(self.device)
+        finally:
+            if full_values is not None:
+                self._a_values = full_values
         for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
             if isinstance(res[k], torch.Tensor):
                 res[k][idx.to(res[k].device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=res[k].device)] = r2[k]
@@ -290,6 +323,12 @@ class HipDensePrimalNormalSolver(BaseSolver):
 
     def solve(self, lp, verbose=0):
         """Solve every problem of ``lp`` (current ``lp.b``, ``lp.c``); results in attributes."""
+        if getattr(self, "_delegate", None) is not None:
+            d = self._delegate
+            d.solve(lp, verbose=verbose)
+            for k in ("x", "y", "z", "status", "iters", "primal_obj", "dual_obj"):
+                setattr(self, k, getattr(d, k))
+            return self.status
         if int(lp.nrows) != self.m or int(lp.ncols) != self.n:
             raise ValueError("LP shape changed since init(): (%d,%d) vs (%d,%d)" % (lp.nrows, lp.ncols, self.m, self.n))
         if self._handle is None:
@@ -372,12 +411,25 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
         self.device = _require_gpu(self.device)
         L = _native.lib()
         m, n = int(lp.nrows), int(lp.ncols)
-        if hasattr(lp.A, "tocsr"):
-            A = sp.csr_matrix(lp.A.tocsr())
+        self._a_perm = None
+        if getattr(lp.A, "nproblems", 1) > 1:
+            # per-problem values on one structure (SparseMatrix.data[nproblems, nnz], pycllp/lp.py:16-54): the structure
+            # comes from the coordinate lists, the values of problem 0 only stand in at init
+            rows, cols = np.asarray(lp.A._rows), np.asarray(lp.A._cols)
+            perm = np.lexsort((cols, rows))
+            if perm.size and ((np.diff(rows[perm]) == 0) & (np.diff(cols[perm]) == 0)).any():
+                raise ValueError("per-problem A: duplicate (row, column) entries in the structure")
+            self._a_perm = perm
+            indptr = np.zeros(m + 1, dtype=np.int64)
+            np.add.at(indptr, rows + 1, 1)
+            A = sp.csr_matrix((np.asarray(lp.A.data[0], dtype=np.float64)[perm], cols[perm], np.cumsum(indptr)), shape=(m, n))
         else:
-            A = sp.csr_matrix(np.asarray(lp.A.todense() if hasattr(lp.A, "todense") else lp.A, dtype=np.float64))
-        A = sp.csr_matrix(A, shape=(m, n))
-        A.sum_duplicates(); A.eliminate_zeros(); A.sort_indices()
+            if hasattr(lp.A, "tocsr"):
+                A = sp.csr_matrix(lp.A.tocsr())
+            else:
+                A = sp.csr_matrix(np.asarray(lp.A.todense() if hasattr(lp.A, "todense") else lp.A, dtype=np.float64))
+            A = sp.csr_matrix(A, shape=(m, n))
+            A.sum_duplicates(); A.eliminate_zeros(); A.sort_indices()
         if verbose > 0:
             print("Initializing HipSparsePrimalNormalSolver (m=%d, n=%d, nnz=%d) on %s" % (m, n, A.nnz, self.device))
         self._free()
@@ -391,8 +443,32 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
         self._handle = h
         self.m, self.n = m, n
         self.buffers = {}
+        self._a_values = None
+
+    def solve(self, lp, verbose=0):
+        if self._a_perm is not None:
+            data = np.asarray(lp.A.data, dtype=np.float64)
+            if data.shape != (int(lp.nproblems), self._a_perm.size):
+                raise ValueError("per-problem A: lp.A.data must be [nproblems, nnz] = (%d, %d); got %r"
+                                 % (lp.nproblems, self._a_perm.size, data.shape))
+            self._a_values = torch.as_tensor(np.ascontiguousarray(data[:, self._a_perm]), device=self.device)
+        return super(HipSparsePrimalNormalSolver, self).solve(lp, verbose=verbose)
 
     def _launch(self, B, b, c, buf, o):
+        if self._a_perm is not None:
+            av = self._a_values
+            if av is None or av.shape[0] < B:
+                raise ValueError("per-problem A: no values for this batch (use lp.solve(solver))")
+            # a chunk of the host pipeline, or the sub-batch of an hsd='auto' re-solve, addresses its rows of the values
+            # through the offset of its b inside the full batch
+            lo = 0
+            if getattr(self, "_a_row0", None) is not None:
+                lo = self._a_row0
+            _native.check(_native.lib().pycllp_hip_sparse_solve_batch(
+                self._handle, B, self._ptr(av[lo:lo + B]), self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
+                self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),
+                self._ptr(buf["iters"]), ctypes.byref(o), self._stream_ptr()), "pycllp_hip_sparse_solve_batch")
+            return
         _native.check(_native.lib().pycllp_hip_sparse_solve(
             self._handle, B, self._ptr(b), self._ptr(c), self._ptr(buf["x"]), self._ptr(buf["y"]),
             self._ptr(buf["z"]), self._ptr(buf["pobj"]), self._ptr(buf["dobj"]), self._ptr(buf["status"]),

@@ -129,3 +129,68 @@ def test_packed_result_layout_round_trip():
             views["x"][:] = 1.5; views["status"][:] = 7; views["z"][:] = -2.0
             again = s.unpack(packed[:lay["_gather_bytes"]].clone(), lay)      # what a peer would receive
             assert float(again["x"].sum()) == 1.5 * B * 13 and int(again["status"].sum()) == 7 * B
+
+
+def _surface_cases():
+    import scipy.sparse as sp
+    from conftest import golden
+    from pycllp_amd import lp as our_lp
+    g = golden("reference_lp_surface.npz")
+    for key in [str(k) for k in g["keys"]]:
+        A = our_lp.SparseMatrix(matrix=sp.coo_matrix(g[key + "_in_A"]))
+        f = float(g[key + "_in_f"])
+        if str(g[key + "_in_kind"]) == "standard":
+            lp = our_lp.StandardLP(A, g[key + "_in_b"], g[key + "_in_c"], f).to_equality_form()
+        else:
+            lp = our_lp.EqualityLP(A, g[key + "_in_b"], g[key + "_in_c"], f)
+        yield key, g, lp
+
+
+def test_lp_containers_show_the_surface_recorded_from_the_reference_objects():
+    """tests/golden/reference_lp_surface.npz holds what REFERENCE-built LP objects (pycllp/lp.py) exposed to
+    HipDensePrimalNormalSolver.consume for a set of raw inputs (tools/check_reference_boundary.py, build container):
+    this package's own containers must expose the same values for the same inputs."""
+    from pycllp_amd.solvers.hip import HipDensePrimalNormalSolver
+    n = 0
+    for key, g, lp in _surface_cases():
+        s = HipDensePrimalNormalSolver.consume(lp)
+        assert [s["m"], s["n"], s["nproblems"]] == list(g[key + "_shape"])
+        for k in ("A", "b", "c", "f"):
+            np.testing.assert_array_equal(s[k], g[key + "_" + k])
+        n += 1
+    assert n == 4
+
+
+def test_general_lp_to_standard_form_matches_the_reference_fixtures():
+    """tests/golden/general_lp.npz: StandardLPs the REFERENCE's GeneralLP.to_standard_form (pycllp/lp.py:725-792) returned for
+    the case of its own tests/test_lp.py:236-250 and two more (tools/gen_lp_fixtures.py, build container)."""
+    import scipy.sparse as sp
+    from conftest import golden
+    from pycllp_amd.lp import GeneralLP
+    g = golden("general_lp.npz")
+    for key in [str(k) for k in g["keys"]]:
+        lp = GeneralLP(SparseMatrix(matrix=sp.coo_matrix(g[key + "_A"])), b=g[key + "_b"], c=g[key + "_c"], a=g[key + "_a"],
+                       l=g[key + "_l"], f=0.0)
+        slp = lp.to_standard_form()
+        np.testing.assert_allclose(slp.A.todense(), g[key + "_std_A"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(slp.b, g[key + "_std_b"], rtol=1e-15, atol=1e-15)
+        np.testing.assert_allclose(slp.c, g[key + "_std_c"], rtol=0, atol=0)
+        np.testing.assert_allclose(slp.f, g[key + "_std_f"], rtol=1e-15, atol=1e-15)
+    with pytest.raises(ValueError):
+        GeneralLP(SparseMatrix(matrix=sp.coo_matrix(np.eye(2))), b=[1.0, 1.0], c=[1.0, 1.0], l=[-np.inf, 0.0], f=0.0).to_standard_form()
+
+
+def test_per_problem_values_of_A_in_the_containers():
+    """SparseMatrix.data[nproblems, nnz] (pycllp/lp.py:16-54): one set of values per problem is accepted (the reference's
+    LP classes refuse it, lp.py:335-336), carried through to_equality_form, and a mismatch raises."""
+    rs = np.random.RandomState(0)
+    rows, cols = np.array([0, 0, 1, 1, 1]), np.array([0, 2, 0, 1, 2])
+    data = rs.rand(4, 5)
+    lp = StandardLP(SparseMatrix(rows, cols, data), rs.rand(4, 2), rs.rand(4, 3), 0.0)
+    elp = lp.to_equality_form()
+    assert elp.A.nproblems == 4 and elp.ncols == 5 and elp.nrows == 2
+    for k in range(4):
+        D = elp.A.todense(k)
+        assert D[0, 0] == data[k, 0] and D[1, 1] == data[k, 3] and D[0, 3] == 1.0 and D[1, 4] == 1.0
+    with pytest.raises(ValueError):
+        StandardLP(SparseMatrix(rows, cols, data), rs.rand(3, 2), rs.rand(3, 3), 0.0)
