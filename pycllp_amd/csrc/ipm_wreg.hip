@@ -60,12 +60,16 @@ __device__ __forceinline__ void park(PBlk& p, const double4_t& v) {
 }
 __device__ __forceinline__ double unpark(const PBlk& p, int r) { return __hiloint2double(p.h[2 * r + 1], p.h[2 * r]); }
 
-constexpr int HB = 4;            // 16 x 16 blocks per Gram staging chunk (8 KB of LDS)
-constexpr int STAGE_D = HB * 256;
-constexpr int TILE_OFF = 512, RR_OFF = 800;   // aliases inside the stage (free once the blocks are in registers)
-constexpr int WL = 128;          // doubles reserved per packed W block (120 used: strictly lower triangle, row i at i(i-1)/2)
+// stage proper: N-vector staging; during factor/solve t, x and z parked at 0, NP, 2 NP and the stride-17 tile of the current
+// diagonal block behind them
+constexpr int TILE_D = 272;
+__host__ __device__ constexpr int tile_off(int NQ) { return 192 * NQ > 768 ? 192 * NQ : 768; }
+__host__ __device__ constexpr int stage_d(int NQ) { return tile_off(NQ) + TILE_D; }
+constexpr int HB = 8;            // 16 x 16 blocks per Gram staging chunk: the stage and, behind it, the still unused W area (16 KB)
+constexpr int WL = 144;          // doubles per diagonal-block slot: first the ORIGINAL diagonal block of M (lower triangle with
+                                 // diagonal, row i at i(i+1)/2: 136), from stage K on W_K (strictly lower triangle, row i at i(i-1)/2)
 constexpr int MAX_NQ = 8;
-constexpr int META_COFF = MAX_NQ, META_SEG = 2 * MAX_NQ, META_DSEG = META_SEG + 24, META_N = META_DSEG + 24;
+constexpr int META_COFF = MAX_NQ, META_SEG = 2 * MAX_NQ, META_N = META_SEG + 16;
 
 template <int MB>
 struct WGeo {
@@ -75,28 +79,31 @@ struct WGeo {
     static constexpr int NBLK = MB * (MB - 1) / 2;
     // off-diagonal block (K, I), K < I, of U = L'
     __host__ __device__ static constexpr int bix(int K, int I) { return K * MB - K * (K + 1) / 2 + (I - K - 1); }
-    // Gram staging chunks: block row K of U holds the blocks I = K+1 .. MB-1, staged HB at a time
-    __host__ __device__ static constexpr int nch(int K) { return (MB - 1 - K + HB - 1) / HB; }
-    __host__ __device__ static constexpr int chbase(int K) { int s = 0; for (int k = 0; k < K; k++) s += nch(k); return s; }
-    static constexpr int NCHUNK = chbase(MB);
-    static constexpr int WAVE_D(int NQ) { return STAGE_D + 64 * NQ + 6 * MP + MB * WL; }   // per-wave LDS doubles
+    // Gram staging chunks: the off-diagonal blocks in bix order, HB at a time; chunk NCHUNK = the diagonal blocks
+    static constexpr int NCHUNK = (NBLK + HB - 1) / HB;
+    static constexpr int WAVE_D(int NQ) { return stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL; }   // per-wave LDS doubles
 };
 
 // Device view of the tables of one constraint matrix (built by wreg_plan_create).
 struct WregTab {
     int m, n, nnz;
-    int rmax, n_ent, n_term;
-    int meta[META_N];     // [0..8) ELL depth of column register q, [META_COFF..) its first ELL slot, [META_SEG..) first Gram
-                          // entry of staging chunk i (chunks in (K, ch) order; NCHUNK + 1 used), [META_DSEG..) first Gram
-                          // entry of diagonal block K (MB + 1 used) -- copied to LDS
+    int rmax, n_lev, n_term;
+    int meta[META_N];     // [0..8) ELL depth of column register q, [META_COFF..) its first ELL slot, [META_SEG..) first level
+                          // (index into lev) of Gram group g: the NCHUNK staging chunks of off-diagonal blocks, then the
+                          // diagonal blocks; NCHUNK + 2 used -- copied to LDS
     const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
     // A by columns in ELL form over column POSITIONS: the columns are dealt to the (lane, register) positions of the
-    // N-vectors sorted by length, so that each register's 64 columns are about equally long (JDS); colmap[pos] = column
-    const double* ec_val; const unsigned short* ec_row; const unsigned short* colmap; int ctot;
-    const unsigned* e_ptr; const unsigned short* e_dst;   // Gram entries: term range, offset inside the stage / tile
-    const double* t_w; const unsigned short* t_col;       // Gram terms: a_ij a_kj and the column j
-    int o_csr_val, o_ec_val, o_t_w, o_wave, o_e_ptr, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
-        o_e_dst, o_t_col;                                 // LDS byte offsets
+    // N-vectors sorted by length, so that each register's 64 columns are about equally long (JDS); colmap[pos] = 8 x column
+    const double* ec_val; const unsigned short* ec_row; const unsigned* colmap; int ctot;   // (a byte offset; PAD_OFF for pos >= n)
+    // Gram terms a_ij a_kj d_j of the strictly lower triangle of M, one record per term: weight a_ij a_kj, column position
+    // of j, destination offset inside the group's staging area.  Inside a group the terms are ordered by LEVEL = rank of
+    // the term inside its entry (i, k): level 0 holds the first term of every entry, level 1 the second term of the
+    // entries that have one, ...; lev[] holds the item boundaries, level l of the table = items [lev[l], lev[l + 1]).
+    // Destinations are distinct inside a level, so a level is one flat pass with no inner loop; level 0 stores, the
+    // later levels accumulate in the same order a per-entry loop would.
+    const double* t_w; const unsigned* t_cd; const int* lev;     // t_cd = column position | destination << 16
+    int o_csr_val, o_ec_val, o_t_w, o_wave, o_lev, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
+        o_t_cd;                                           // LDS byte offsets
     int wave_doubles, lds_bytes;
 };
 
@@ -143,11 +150,176 @@ __device__ __forceinline__ double wmax(double v) {
     return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
 }
 
+// ---- per-LP vectors in global memory through buffer descriptors ------------------------------------------------
+// descriptor (4 SGPRs) of one LP's row of a [B][len] array + a 32-bit byte offset per lane: no 64-bit per-lane pointers
+// (which the compiler hoists out of the iteration loop and spills), and offsets past the row read 0 / drop the store, so
+// the padded positions of the N-vectors (offset PAD_OFF) need neither a branch nor a select
+typedef int int2_t __attribute__((ext_vector_type(2)));
+constexpr unsigned PAD_OFF = 0x7ffffff0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* row, int len) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, row ? 8 * len : 0, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const int2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return __hiloint2double(v.y, v.x);
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t r, unsigned off, double d) {
+    int2_t v; v.x = __double2loint(d); v.y = __double2hiint(d);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+}
+
+// ---- 64-bit DPP (gfx90a+: the DP ALU takes row_newbcast) ---------------------------------------------------------
+// The compiler builds a row broadcast of a double from two v_mov_b32_dpp and feeds the copy to the FMA; the hardware can
+// broadcast inside the 64-bit instruction itself.  The s_nop covers the VALU-write -> DPP-read hazard (2 wait states),
+// which the hazard recogniser does not see through inline asm.
+#define DPP_STR_(x) #x
+#define DPP_STR(x) DPP_STR_(x)
+// v of lane K of each 16-lane row
+template <int K>
+__device__ __forceinline__ double bcast64(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" DPP_STR(%2) " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+// Pivot step J of the 16-step chain: Wd[k] += (u of lane k of the row) * nli for k = J+1 .. 15, one fused 64-bit DPP FMA
+// each.  ONE asm statement per step, with a leading s_nop: the compiler may have produced u (or moved it between register
+// files) in the instruction just before, and the hazard recogniser does not look inside inline asm.
+template <int J>
+__device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nli) {
+    asm volatile("s_nop 1\n\t"
+                 ".if 1 > %18\n\tv_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 2 > %18\n\tv_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 3 > %18\n\tv_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 4 > %18\n\tv_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 5 > %18\n\tv_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 6 > %18\n\tv_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 7 > %18\n\tv_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 8 > %18\n\tv_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 9 > %18\n\tv_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 10 > %18\n\tv_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 11 > %18\n\tv_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 12 > %18\n\tv_fmac_f64_dpp %12, %16, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 13 > %18\n\tv_fmac_f64_dpp %13, %16, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 14 > %18\n\tv_fmac_f64_dpp %14, %16, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 15 > %18\n\tv_fmac_f64_dpp %15, %16, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15])
+                 : "v"(u), "v"(nli), "n"(J));
+}
+// Step J of the triangular inverse in the A-operand layout: Ws[s] += (Ws[s] of lane J of the row) * nl for the registers
+// s <= J / 4 (columns 4s + q <= J)
+template <int J>
+__device__ __forceinline__ void winv_step(double (&Ws)[4], double nl) {
+    asm volatile("s_nop 1\n\t"
+                 ".if 0 <= %5\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 4 <= %5\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 8 <= %5\n\tv_fmac_f64_dpp %2, %2, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 12 <= %5\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 : "+v"(Ws[0]), "+v"(Ws[1]), "+v"(Ws[2]), "+v"(Ws[3]) : "v"(nl), "n"(J));
+}
+
+// ---- batched LDS reads -----------------------------------------------------------------------------------------
+// One wavefront alone on its SIMD hides no latency by itself, and in this kernel's register-starved regions the compiler
+// schedules every LDS read right in front of its use with its own s_waitcnt (the sched_group_barrier hints are not
+// honoured there): a run of N reads then costs N round trips.  These helpers issue the whole run and wait ONCE.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+#define LDS_RD_(i) "ds_read_b64 %" #i ", %16 offset:%17+%18*" #i "\n\t"
+// o[i] = *(double*)(a + OFF0 + STRIDE i), i < 16 (byte address / offsets)
+template <int OFF0, int STRIDE>
+__device__ __forceinline__ void lds_run16(unsigned a, double* o) {
+    asm volatile(LDS_RD_(0) LDS_RD_(1) LDS_RD_(2) LDS_RD_(3) LDS_RD_(4) LDS_RD_(5) LDS_RD_(6) LDS_RD_(7) LDS_RD_(8) LDS_RD_(9)
+                 LDS_RD_(10) LDS_RD_(11) LDS_RD_(12) LDS_RD_(13) LDS_RD_(14) LDS_RD_(15) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                 : "v"(a), "n"(OFF0), "n"(STRIDE) : "memory");
+}
+#undef LDS_RD_
+#define LDS_RD2_(i) "ds_read2_b64 %" #i ", %24 offset0:2*" #i " offset1:2*" #i "+1\n\t"
+#define LDS_RD1_(i, k) "ds_read_b64 %" #i ", %25 offset:%26+8*" #k "\n\t"
+// one round trip for a row of the diagonal-block tile and of the original block: t[0..8) <- 16 consecutive doubles at at
+// (8-byte aligned), r[0..16) <- 16 consecutive doubles at ar + OFF (the slot offset folded into the instruction)
+template <int OFF>
+__device__ __forceinline__ void lds_tile_and_raw(unsigned at, unsigned ar, double2_t (&t)[8], double (&r)[16]) {
+    asm volatile(LDS_RD2_(0) LDS_RD2_(1) LDS_RD2_(2) LDS_RD2_(3) LDS_RD2_(4) LDS_RD2_(5) LDS_RD2_(6) LDS_RD2_(7)
+                 LDS_RD1_(8, 0) LDS_RD1_(9, 1) LDS_RD1_(10, 2) LDS_RD1_(11, 3) LDS_RD1_(12, 4) LDS_RD1_(13, 5) LDS_RD1_(14, 6) LDS_RD1_(15, 7)
+                 LDS_RD1_(16, 8) LDS_RD1_(17, 9) LDS_RD1_(18, 10) LDS_RD1_(19, 11) LDS_RD1_(20, 12) LDS_RD1_(21, 13) LDS_RD1_(22, 14) LDS_RD1_(23, 15)
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                   "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]),
+                   "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]), "=&v"(r[14]), "=&v"(r[15])
+                 : "v"(at), "v"(ar), "n"(OFF) : "memory");
+}
+#undef LDS_RD2_
+#undef LDS_RD1_
+// eight ELL slots: o[k] = *(double*)(ad + 512 k), r[k] = *(unsigned short*)(au + 128 k)
+__device__ __forceinline__ void lds_ell8(unsigned ad, unsigned au, double (&o)[8], unsigned (&r)[8]) {
+    asm volatile("ds_read_b64 %0, %16\n\tds_read_b64 %1, %16 offset:512\n\tds_read_b64 %2, %16 offset:1024\n\tds_read_b64 %3, %16 offset:1536\n\t"
+                 "ds_read_b64 %4, %16 offset:2048\n\tds_read_b64 %5, %16 offset:2560\n\tds_read_b64 %6, %16 offset:3072\n\tds_read_b64 %7, %16 offset:3584\n\t"
+                 "ds_read_u16 %8, %17\n\tds_read_u16 %9, %17 offset:128\n\tds_read_u16 %10, %17 offset:256\n\tds_read_u16 %11, %17 offset:384\n\t"
+                 "ds_read_u16 %12, %17 offset:512\n\tds_read_u16 %13, %17 offset:640\n\tds_read_u16 %14, %17 offset:768\n\tds_read_u16 %15, %17 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(ad), "v"(au) : "memory");
+}
+// four consecutive CSR slots of two rows: v[0..2) <- four doubles at av0, v[2..4) <- at av1; c[0..4) <- four u16 at ac0, c[4..8) <- at ac1
+__device__ __forceinline__ void lds_rows4x2(unsigned av0, unsigned ac0, unsigned av1, unsigned ac1, double2_t (&v)[4], unsigned (&c)[8]) {
+    asm volatile("ds_read2_b64 %0, %12 offset1:1\n\tds_read2_b64 %1, %12 offset0:2 offset1:3\n\t"
+                 "ds_read2_b64 %2, %14 offset1:1\n\tds_read2_b64 %3, %14 offset0:2 offset1:3\n\t"
+                 "ds_read_u16 %4, %13\n\tds_read_u16 %5, %13 offset:2\n\tds_read_u16 %6, %13 offset:4\n\tds_read_u16 %7, %13 offset:6\n\t"
+                 "ds_read_u16 %8, %15\n\tds_read_u16 %9, %15 offset:2\n\tds_read_u16 %10, %15 offset:4\n\tds_read_u16 %11, %15 offset:6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]),
+                   "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                 : "v"(av0), "v"(ac0), "v"(av1), "v"(ac1) : "memory");
+}
+__device__ __forceinline__ void lds_gather4_u16(const unsigned (&a)[4], unsigned (&o)[4]) {
+    asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %5\n\tds_read_u16 %2, %6\n\tds_read_u16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
+__device__ __forceinline__ void lds_gather8(const unsigned (&a)[8], double (&o)[8]) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+}
+// o[k] = *(double*)a[k], u[k] = *(double*)(a[k] + DELTA)
+template <int DELTA>
+__device__ __forceinline__ void lds_gather8_pair(const unsigned (&a)[8], double (&o)[8], double (&u)[8]) {
+    asm volatile("ds_read_b64 %0, %16\n\tds_read_b64 %1, %17\n\tds_read_b64 %2, %18\n\tds_read_b64 %3, %19\n\t"
+                 "ds_read_b64 %4, %20\n\tds_read_b64 %5, %21\n\tds_read_b64 %6, %22\n\tds_read_b64 %7, %23\n\t"
+                 "ds_read_b64 %8, %16 offset:%24\n\tds_read_b64 %9, %17 offset:%24\n\tds_read_b64 %10, %18 offset:%24\n\tds_read_b64 %11, %19 offset:%24\n\t"
+                 "ds_read_b64 %12, %20 offset:%24\n\tds_read_b64 %13, %21 offset:%24\n\tds_read_b64 %14, %22 offset:%24\n\tds_read_b64 %15, %23 offset:%24\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(DELTA) : "memory");
+}
+// gathers: o[k] = *(double*)a[k] resp. o[k] = *(unsigned*)a[k]
+__device__ __forceinline__ void lds_gather4(const unsigned (&a)[4], double (&o)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
+__device__ __forceinline__ void lds_gather4x2(const unsigned (&a)[4], const unsigned (&b)[4], double (&o)[4], double (&u)[4]) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
+}
+// o[k] = *(double*)a[k], c[k] = *(unsigned*)b[k]
+__device__ __forceinline__ void lds_gather4_d_u(const unsigned (&a)[4], const unsigned (&b)[4], double (&o)[4], unsigned (&c)[4]) {
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                 "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
+}
+
 // ---- the per-wave machinery ------------------------------------------------------------------------------------
 template <int MB, int NQ>
 struct WReg {
     using G = WGeo<MB>;
-    static constexpr int MP = G::MP, MR = G::MR, MPL = G::MPL, NP = 64 * NQ;
+    static constexpr int MP = G::MP, MR = G::MR, MPL = G::MPL, NP = 64 * NQ, STAGE_D = stage_d(NQ), TILE_OFF = tile_off(NQ);
 
     // Off-diagonal blocks [bix(K, I)], K < I.  Life of a block: gram() parks the original M_KI in P; the trailing update
     // of stage_() 0 takes it out as an MFMA accumulator (U) where it stays through the following stages' updates; panel K
@@ -156,136 +328,177 @@ struct WReg {
     PBlk P[G::NBLK > 0 ? G::NBLK : 1];
     // LDS: shared tables (A by rows and by columns in compact form, Gram entries/terms)
     const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
-    const double* ec_val; const unsigned short* ec_row; const unsigned short* colmap;
-    const unsigned* e_ptr; const unsigned short* e_dst;
-    const double* t_w; const unsigned short* t_col;
+    const double* ec_val; const unsigned short* ec_row; const unsigned* colmap;
+    const double* t_w; const unsigned* t_cd; const int* lev;
     const int* meta;
     // LDS: this wave's area, every array at a COMPILE-TIME offset from the one base pointer W0 -- so that the address
     // arithmetic of all of them folds into a handful of lane-dependent bases plus immediate offsets (as separate
     // run-time pointers every (array, index pattern) pair costs a VGPR for the whole kernel)
     double* W0;
     __device__ __forceinline__ double* stage_() const { return W0; }                            // [STAGE_D] Gram staging; aliases: vx = stage_()[0..NP), tile, rr
-    __device__ __forceinline__ double* vd_() const { return W0 + STAGE_D; }                     // [NP] d = x/z
-    __device__ __forceinline__ double* ys_() const { return W0 + STAGE_D + NP; }                // [MP] y
-    __device__ __forceinline__ double* bs_() const { return W0 + STAGE_D + NP + MP; }           // [MP] b
-    __device__ __forceinline__ double* um_() const { return W0 + STAGE_D + NP + 2 * MP; }       // [MP] solve vector in/out
-    __device__ __forceinline__ double* rdv_() const { return W0 + STAGE_D + NP + 3 * MP; }      // [MP] 1/D
-    __device__ __forceinline__ double* flr_() const { return W0 + STAGE_D + NP + 4 * MP; }      // [MP] per-column pivot floors (HSD)
-    __device__ __forceinline__ double* adv_() const { return W0 + STAGE_D + NP + 5 * MP; }      // [MP] D (the floored pivots)
-    __device__ __forceinline__ double* wl_() const { return W0 + STAGE_D + NP + 6 * MP; }       // [MB][WL] W_K = L_KK^-1, strict lower triangle packed by rows
-    int lane, q, c16, m, n, rmax;
+    __device__ __forceinline__ double* wl_() const { return W0 + STAGE_D; }                     // [MB][WL] diagonal-block slots (see WL); with the stage in front of it: the Gram staging area
+    __device__ __forceinline__ double* vd_() const { return W0 + STAGE_D + MB * WL; }           // [NP] d = x/z
+    __device__ __forceinline__ double* ys_() const { return W0 + STAGE_D + MB * WL + NP; }                // [MP] y
+    __device__ __forceinline__ double* bs_() const { return W0 + STAGE_D + MB * WL + NP + MP; }           // [MP] b
+    __device__ __forceinline__ double* um_() const { return W0 + STAGE_D + MB * WL + NP + 2 * MP; }       // [MP] solve vector in/out
+    __device__ __forceinline__ double* rdv_() const { return W0 + STAGE_D + MB * WL + NP + 3 * MP; }      // [MP] 1/D
+    __device__ __forceinline__ double* flr_() const { return W0 + STAGE_D + MB * WL + NP + 4 * MP; }      // [MP] per-column pivot floors (HSD)
+    mutable int lane, q, c16;
+    int m, n, rmax;
+    // Every lane-dependent LDS address in this kernel is `lane`, `q` or `c16` times something plus a constant.  Left alone the
+    // compiler computes each of them once, outside the iteration loop, and then has dozens of kernel-lifetime address
+    // registers to spill; pin() makes the three values opaque at the point of the call, so that what is derived from them
+    // below is recomputed there (a VALU instruction or two) and dies after its use.
+    // byte offset inside an LP's row of the column at position lane + 64 qq of the N-vectors (PAD_OFF: padded position)
+    __device__ __forceinline__ unsigned coff(int qq) const { return colmap[lane + 64 * qq]; }
+    __device__ __forceinline__ void pin() const { asm volatile("" : "+v"(lane), "+v"(q), "+v"(c16)); }
 
     // out_q = (A'u)_j for the column at position lane + 64 q (see colmap), u in LDS.  ELL: slot t of register q sits at
     // (coff_q + t) 64 + lane -- an immediate offset from one lane-dependent base; padded slots hold value 0, row 0.
     __device__ __forceinline__ void At(const double* u, double (&out)[NQ]) const {
+        pin();
+        const unsigned ub = lds_addr(u), vb = lds_addr(ec_val) + 8 * lane, rb = lds_addr(ec_row) + 2 * lane;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             const int cm = __builtin_amdgcn_readfirstlane(meta[qq]);
-            const int base = __builtin_amdgcn_readfirstlane(meta[META_COFF + qq]) * 64 + lane;
+            const int cof = __builtin_amdgcn_readfirstlane(meta[META_COFF + qq]);
             double a0 = 0.0, a1 = 0.0;
-            int t = 0;
-            for (; t + 1 < cm; t += 2) {
-                a0 = fma(ec_val[base + 64 * t], u[ec_row[base + 64 * t]], a0);
-                a1 = fma(ec_val[base + 64 * t + 64], u[ec_row[base + 64 * t + 64]], a1);
+            for (int t0 = 0; t0 < cm; t0 += 8) {          // eight slots per round trip; slots >= cm belong to the next register: masked
+                double av[8], uv[8]; unsigned rw[8], ua[8];
+                lds_ell8(vb + 512 * (cof + t0), rb + 128 * (cof + t0), av, rw);
+#pragma unroll
+                for (int k = 0; k < 8; k++) ua[k] = ub + 8 * ((t0 + k < cm) ? rw[k] : 0u);
+                lds_gather8(ua, uv);
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    a0 = fma((t0 + k < cm) ? av[k] : 0.0, uv[k], a0);
+                    a1 = fma((t0 + k + 1 < cm) ? av[k + 1] : 0.0, uv[k + 1], a1);
+                }
             }
-            if (t < cm) a0 = fma(ec_val[base + 64 * t], u[ec_row[base + 64 * t]], a0);
             out[qq] = a0 + a1;
         }
     }
     // (A v)_i for the rows i = lane + 64 r2 of this lane, v staged in LDS; with DIAG also diag(A diag(d) A')_i (d in vd_();
-    // padded rows get 1: identity rows of M) from the same pass over the row
+    // padded rows get 1: identity rows of M) from the same pass over the row.  Four slots of both rows per round trip.
     template <bool DIAG>
     __device__ __forceinline__ void Arow(const double* v, double (&out)[MR], double (&md)[MR]) const {
-        int ptr[MR], len[MR];
-#pragma unroll
-        for (int r2 = 0; r2 < MR; r2++) {
-            ptr[r2] = csr_ptr[lane + 64 * r2]; len[r2] = csr_len[lane + 64 * r2];
-            out[r2] = 0.0; md[r2] = 0.0;
+        static_assert(MR == 2, "two rows per lane");
+        unsigned pl[4];
+        pin();
+        {
+            const unsigned pa[4] = {lds_addr(csr_ptr + lane), lds_addr(csr_ptr + lane + 64), lds_addr(csr_len + lane), lds_addr(csr_len + lane + 64)};
+            lds_gather4_u16(pa, pl);
         }
-#pragma unroll 4
-        for (int t = 0; t < rmax; t++) {
+        const unsigned vb = lds_addr(v), cvb = lds_addr(csr_val), ccb = lds_addr(csr_col);
+        double o0[MR] = {0.0, 0.0}, o1[MR] = {0.0, 0.0}, m0[MR] = {0.0, 0.0}, m1[MR] = {0.0, 0.0};
+        for (int t0 = 0; t0 < rmax; t0 += 4) {
+            double2_t av[4]; unsigned cc[8], ga[8]; double a[8], xv[8], dv[8];
+            lds_rows4x2(cvb + 8 * (pl[0] + t0), ccb + 2 * (pl[0] + t0), cvb + 8 * (pl[1] + t0), ccb + 2 * (pl[1] + t0), av, cc);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool on = t0 + (k & 3) < (int)pl[2 + (k >> 2)];
+                a[k] = on ? av[k >> 1][k & 1] : 0.0;
+                ga[k] = vb + 8 * (on ? cc[k] : 0u);
+            }
+            if (DIAG) lds_gather8_pair<8 * (STAGE_D + MB * WL)>(ga, xv, dv);     // vd_() sits STAGE_D + MB WL doubles behind the stage
+            else lds_gather8(ga, xv);
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
-                const bool on = t < len[r2];
-                const int p = on ? ptr[r2] + t : 0;
-                const double a = on ? csr_val[p] : 0.0;
-                const int cidx = csr_col[p];
-                out[r2] = fma(a, v[cidx], out[r2]);
-                if (DIAG) md[r2] = fma(a * a, vd_()[cidx], md[r2]);
-            }
-        }
-        if (DIAG) {
-#pragma unroll
-            for (int r2 = 0; r2 < MR; r2++) md[r2] = (lane + 64 * r2 < m) ? md[r2] : 1.0;
-        }
-    }
-
-    // dstbuf[e_dst[e]] (+)= value of Gram entry e (sum over its terms of a_ij a_kj d_j) for the entries [e0, e1): FOUR
-    // entries per lane per trip with every table read of the trip issued before the first use (one wavefront alone on its
-    // SIMD hides no latency by itself); the first term of an entry -- for most entries the only one -- is on that fast
-    // path, further terms in a short tail loop
-    template <bool ADD>
-    __device__ __forceinline__ void scatter_entries(double* dstbuf, int e0, int e1) const {
-        const double* vdp = vd_();
-        for (int e = e0 + lane; e < e1; e += 256) {
-            unsigned p0[4], p1[4];
-            int dst[4];
-            bool on[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                on[k] = e + 64 * k < e1;
-                const int ek = on[k] ? e + 64 * k : e0;
-                p0[k] = e_ptr[ek]; p1[k] = e_ptr[ek + 1]; dst[k] = e_dst[ek];
-            }
-            double wv[4]; int cj[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { wv[k] = t_w[p0[k]]; cj[k] = t_col[p0[k]]; }
-            double acc[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) acc[k] = wv[k] * vdp[cj[k]];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                for (unsigned p = p0[k] + 1; p < p1[k]; p++) acc[k] = fma(t_w[p], vdp[t_col[p]], acc[k]);
-                if (on[k]) { if (ADD) dstbuf[dst[k]] += acc[k]; else dstbuf[dst[k]] = acc[k]; }
-            }
-        }
-    }
-
-    // Off-diagonal blocks of M = A diag(d) A' (d in vd_()) -> U, one staging chunk of <= HB blocks at a time.  The diagonal
-    // blocks are NOT kept in registers: factor() rebuilds block K from the tables when its turn comes (diag_from_tables).
-    __device__ __forceinline__ void gram() {
-        static_for<0, MB>([&](auto Kc) {
-            constexpr int K = decltype(Kc)::value;
-            static_for<0, G::nch(K)>([&](auto chc) {
-                constexpr int ch = decltype(chc)::value;
-                constexpr int I0 = K + 1 + HB * ch;
-                constexpr int nb = (MB - I0 < HB) ? MB - I0 : HB;
-                constexpr int ci = G::chbase(K) + ch;
-                const double2_t zero = {0.0, 0.0};
-#pragma unroll
-                for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage_())[w * 64 + lane] = zero;
-                wave_lds_sync();
-                scatter_entries<false>(stage_(), __builtin_amdgcn_readfirstlane(meta[META_SEG + ci]),
-                                       __builtin_amdgcn_readfirstlane(meta[META_SEG + ci + 1]));
-                wave_lds_sync();
-#pragma unroll
-                for (int bi = 0; bi < nb; bi++) {
-                    double4_t blk;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) blk[r] = stage_()[bi * 256 + 64 * r + lane];
-                    park(P[G::bix(K, I0 + bi)], blk);
+                o0[r2] = fma(a[4 * r2], xv[4 * r2], o0[r2]); o1[r2] = fma(a[4 * r2 + 1], xv[4 * r2 + 1], o1[r2]);
+                o0[r2] = fma(a[4 * r2 + 2], xv[4 * r2 + 2], o0[r2]); o1[r2] = fma(a[4 * r2 + 3], xv[4 * r2 + 3], o1[r2]);
+                if (DIAG) {
+                    m0[r2] = fma(a[4 * r2] * a[4 * r2], dv[4 * r2], m0[r2]); m1[r2] = fma(a[4 * r2 + 1] * a[4 * r2 + 1], dv[4 * r2 + 1], m1[r2]);
+                    m0[r2] = fma(a[4 * r2 + 2] * a[4 * r2 + 2], dv[4 * r2 + 2], m0[r2]); m1[r2] = fma(a[4 * r2 + 3] * a[4 * r2 + 3], dv[4 * r2 + 3], m1[r2]);
                 }
-                wave_lds_sync();
-            });
-        });
+            }
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < MR; r2++) {
+            out[r2] = o0[r2] + o1[r2];
+            md[r2] = DIAG ? ((lane + 64 * r2 < m) ? m0[r2] + m1[r2] : 1.0) : 0.0;
+        }
     }
 
-    // tile += diagonal block K of M = A diag(d) A' (strict lower triangle from the entry tables, the diagonal from Md)
-    template <int K>
-    __device__ __forceinline__ void diag_from_tables(double* tile, const double (&Md)[MR]) const {
-        scatter_entries<true>(tile, __builtin_amdgcn_readfirstlane(meta[META_DSEG + K]),
-                              __builtin_amdgcn_readfirstlane(meta[META_DSEG + K + 1]));
-        if (q == (K & 3)) tile[c16 * 18] += Md[K >> 2];   // row 16K + c16 lives in lane 16(K&3) + c16 of register K>>2
+    // One level of Gram terms, items [i0, i1): dstbuf[t_dst] = (FIRST) or += t_w d[t_col].  FOUR items per lane per trip,
+    // every table read of the trip issued before the first use (one wavefront alone on its SIMD hides no latency by itself)
+    template <bool FIRST>
+    __device__ __forceinline__ void scatter_level(double* dstbuf, int i0, int i1) const {
+        const unsigned wb = lds_addr(t_w), cb = lds_addr(t_cd), db = lds_addr(vd_()), ob = lds_addr(dstbuf);
+        for (int base = i0; base < i1; base += 256) {
+            unsigned aw[4], ac[4], cd[4]; bool on[4]; double wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ik = base + lane + 64 * k;
+                on[k] = ik < i1;
+                const int ic = on[k] ? ik : i0;
+                aw[k] = wb + 8 * ic; ac[k] = cb + 4 * ic;
+            }
+            lds_gather4_d_u(aw, ac, wv, cd);
+            unsigned ad[4], ao[4]; double dv[4], old[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ad[k] = db + 8 * (cd[k] & 0xffffu); ao[k] = ob + 8 * (cd[k] >> 16); }
+            if (FIRST) lds_gather4(ad, dv); else lds_gather4x2(ad, ao, dv, old);
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (on[k]) dstbuf[cd[k] >> 16] = FIRST ? wv[k] * dv[k] : fma(wv[k], dv[k], old[k]);
+        }
+    }
+    // all levels of Gram group g into dstbuf (zeroed by the caller: entries the structure does not have stay 0)
+    __device__ __forceinline__ void scatter_group(double* dstbuf, int g) const {
+        const int l0 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g]), l1 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g + 1]);
+        if (l0 < l1) {
+            int i0 = __builtin_amdgcn_readfirstlane(lev[l0]), i1 = __builtin_amdgcn_readfirstlane(lev[l0 + 1]);
+            scatter_level<true>(dstbuf, i0, i1);
+            for (int l = l0 + 1; l < l1; l++) {
+                i0 = i1; i1 = __builtin_amdgcn_readfirstlane(lev[l + 1]);
+                scatter_level<false>(dstbuf, i0, i1);
+            }
+        }
+    }
+
+    // M = A diag(d) A' (d in vd_(), diagonal in Md): the off-diagonal blocks go through the staging area HB at a time and are
+    // parked in the accumulator file; the diagonal blocks (lower triangle with diagonal, packed by rows) are left in their
+    // slots of the W area, where factor() picks block K up when its turn comes and then overwrites it with W_K.
+    __device__ __forceinline__ void gram(const double (&Md)[MR]) {
+        static_assert(HB * 256 <= STAGE_D + MB * WL, "staging area too small");
+        static_for<0, G::NCHUNK>([&](auto cc) {
+            constexpr int ci = decltype(cc)::value;
+            constexpr int b0 = HB * ci;
+            constexpr int nb = (G::NBLK - b0 < HB) ? G::NBLK - b0 : HB;
+            const double2_t zero = {0.0, 0.0};
+            pin();
+#pragma unroll
+            for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage_())[w * 64 + lane] = zero;
+            wave_lds_sync();
+            scatter_group(stage_(), ci);
+            wave_lds_sync();
+            static_assert(nb % 4 == 0, "block loads go four blocks (16 registers) at a time");
+#pragma unroll
+            for (int b4 = 0; b4 < nb; b4 += 4) {
+                double v[16];
+                lds_run16<0, 512>(lds_addr(stage_() + b4 * 256 + lane), v);
+#pragma unroll
+                for (int bi = 0; bi < 4; bi++) {
+                    const double4_t blk = {v[4 * bi], v[4 * bi + 1], v[4 * bi + 2], v[4 * bi + 3]};
+                    park(P[b0 + b4 + bi], blk);
+                }
+            }
+            wave_lds_sync();
+        });
+        // diagonal blocks: strict lower triangle from the entry tables, the diagonal from Md (row 16K + i lives in lane
+        // (16K + i) % 64 of register (16K + i) / 64)
+        const double2_t zero = {0.0, 0.0};
+        pin();
+        static_assert((MB * WL) % 128 == 0, "diagonal-block slots are zeroed in whole b128 wavefront stores");
+#pragma unroll
+        for (int w = 0; w < (MB * WL) / 128; w++) ((double2_t*)wl_())[w * 64 + lane] = zero;
+        wave_lds_sync();
+        scatter_group(wl_(), G::NCHUNK);
+#pragma unroll
+        for (int r2 = 0; r2 < MR; r2++) {
+            const int row = lane + 64 * r2, il = row & 15;
+            if (row < MP) wl_()[(row >> 4) * WL + il * (il + 1) / 2 + il] = Md[r2];
+        }
+        wave_lds_sync();
     }
 
     // W_K element [row 4s + q][column c16] -- the TRANSPOSED operand layout -- from the packed copy in LDS
@@ -296,18 +509,19 @@ struct WReg {
         return (c16 < row) ? v : ((c16 == row) ? 1.0 : 0.0);
     }
 
-    // Blocked LDL' of the matrix whose off-diagonal blocks are in U; `diag_add(Kc, tile)` adds the original diagonal
-    // block K (element [i][k], k <= i, at tile[17 i + k]) to the tile that already holds its Schur update.
+    // Blocked LDL' of the matrix whose off-diagonal blocks are parked in P and whose diagonal blocks sit in the slots of
+    // the W area (gram(), or the caller, put them there).
     // RELF: pivot floor of column j is flr_()[j] (LDS) instead of floor_.
     // Returns (wave-uniform) whether the Nocedal-Wright guard would have bitten anywhere.
-    template <bool RELF, typename DiagAdd>
-    __device__ __forceinline__ bool factor(double beta2, double floor_, DiagAdd&& diag_add STAMP_ARGS) {
+    template <bool RELF>
+    __device__ __forceinline__ bool factor(double beta2, double floor_ STAMP_ARGS) {
         // guard verdict, kept as a per-lane integer that every test is folded into AT ONCE (asm pin): left as a boolean the
         // compiler sinks the 16 + 112 compares to the end of the sweep and keeps their operands alive until then
         int viol = 0;
         double* tile = stage_() + TILE_OFF;
         static_for<0, MB>([&](auto Kc) {
             constexpr int K = decltype(Kc)::value;
+            pin();
             // ---- diagonal block K, left-looking: Schur update -sum_{K'<K} (D U_K'K)' U_K'K on the matrix cores ----
             double4_t sch = {0.0, 0.0, 0.0, 0.0};
             static_for<0, K>([&](auto Kp) {
@@ -323,52 +537,54 @@ struct WReg {
             for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = sch[r];
             wave_lds_sync();
             STAMP(2)
-            diag_add(Kc, tile);
-            wave_lds_sync();
-            STAMP(3)
             double Wd[16], Ld[16];
+            {
+                // row c16 of the tile and of the original block (slot K, row offset c16 (c16 + 1) / 2); columns > c16: whatever
+                // follows in the slot (finite, in bounds, never used).  The two lane-dependent addresses are the same for all K.
+                double2_t tl[8]; double rw[16];
+                lds_tile_and_raw<8 * K * WL>(lds_addr(tile + c16 * 17), lds_addr(wl_() + c16 * (c16 + 1) / 2), tl, rw);
 #pragma unroll
-            for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
+                for (int k = 0; k < 8; k++) { Wd[2 * k] = tl[k][0] + rw[2 * k]; Wd[2 * k + 1] = tl[k][1] + rw[2 * k + 1]; }
+            }
+            STAMP(3)
             const double myf = RELF ? flr_()[16 * K + c16] : floor_;
             wave_lds_sync();
-            double rDr[4] = {1.0, 1.0, 1.0, 1.0}, aDr[4] = {1.0, 1.0, 1.0, 1.0}, rdiag = 1.0, adiag = 1.0;
+            double rdiag = 1.0;
             static_for<0, 16>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const double u = Wd[j];
-                const double piv = row_bcast<j>(u);
+                const double piv = bcast64<j>(u);
                 const double aD = fmax(fabs(piv), RELF ? row_bcast<j>(myf) : floor_);
                 const double rD = fast_rcp(aD);
                 const bool below = c16 > j;
                 viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
-                const double li = below ? u * rD : 0.0;
-                static_for<j + 1, 16>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    Wd[k] = fma(-li, row_bcast<k>(u), Wd[k]);
-                });
-                Ld[j] = li;
-                rDr[j >> 2] = (q == (j & 3)) ? rD : rDr[j >> 2];
-                aDr[j >> 2] = (q == (j & 3)) ? aD : aDr[j >> 2];
+                const double nli = below ? -(u * rD) : 0.0;
+                if constexpr (j < 15) chain_step<j>(Wd, u, nli);      // Wd[k] -= l_i u_k, k > j
+                Ld[j] = nli;
                 rdiag = (c16 == j) ? rD : rdiag;
-                adiag = (c16 == j) ? aD : adiag;
-                // select NOW: deferred to the end of the chain (where the scheduler sinks them) the 64 selects keep all
-                // 16 pivots and reciprocals alive and the chain spills
-                asm volatile("" : "+v"(rDr[j >> 2]), "+v"(aDr[j >> 2]), "+v"(rdiag), "+v"(adiag), "+v"(viol));
+                // select NOW: deferred to the end of the chain (where the scheduler sinks them) the selects keep all
+                // 16 reciprocals alive and the chain spills
+                asm volatile("" : "+v"(rdiag), "+v"(viol));
             });
-            if (q == 0) { rdv_()[16 * K + c16] = rdiag; adv_()[16 * K + c16] = adiag; }
+            if (q == 0) rdv_()[16 * K + c16] = rdiag;
             STAMP(4)
-            // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q]; packed copy to LDS ----
+            pin();
+            // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q]; packed copy to LDS (Ld holds -L) ----
             double Ws[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
             static_for<0, 15>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                static_for<0, 4>([&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    if constexpr (4 * s <= j) Ws[s] = fma(-Ld[j], row_bcast<j>(Ws[s]), Ws[s]);
-                });
+                winv_step<j>(Ws, Ld[j]);
             });
+            // (entries on and above the diagonal go to the spare doubles [136, 144) of the slot: one store each, no branch)
 #pragma unroll
-            for (int s = 0; s < 4; s++) if (4 * s + q < c16) wl_()[K * WL + c16 * (c16 - 1) / 2 + 4 * s + q] = Ws[s];
+            for (int s = 0; s < 4; s++) wl_()[K * WL + ((4 * s + q < c16) ? c16 * (c16 - 1) / 2 + 4 * s + q : 136 + s)] = Ws[s];
+            // 1/D in the row form of the accumulator layout (register r <-> pivot 4r + q), back from LDS
+            wave_lds_sync();
+            double rDr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) rDr[r] = rdv_()[16 * K + 4 * r + q];
             // ---- panel: Y_KI = W M_KI = D_K L_IK' on the matrix cores.  The block stays UNSCALED in its accumulator
             //      registers (every use below is an MFMA operand or folds 1/D into a vector): nothing ever writes a
             //      resident block from the VALU side.  Guard test: Y^2 > beta^2 D. ----
@@ -379,7 +595,7 @@ struct WReg {
                 for (int s = 0; s < 4; s++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[s], (K == 0) ? unpark(P[G::bix(K, I)], s) : U[G::bix(K, I)][s], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) viol |= (acc[r] * acc[r] > beta2 * aDr[r]) ? 1 : 0;
+                for (int r = 0; r < 4; r++) viol |= (acc[r] * acc[r] * rDr[r] > beta2) ? 1 : 0;      // Y^2 / D > beta^2
                 asm volatile("" : "+v"(viol));
                 park(P[G::bix(K, I)], acc);
             });
@@ -421,6 +637,7 @@ struct WReg {
     // Forward substitution is column oriented (t_K, once known, is folded into the partial sums of all later block rows
     // and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
     __device__ __forceinline__ void solve() {
+        pin();          // once: the packed-triangle indices of w_elemT (an integer multiply each) are worth keeping for the 16 stages
         double p[MB];
 #pragma unroll
         for (int I = 0; I < MB; I++) p[I] = 0.0;
@@ -484,15 +701,14 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
     double* s_csr_val = (double*)(lraw + T.o_csr_val);
     double* s_ec_val = (double*)(lraw + T.o_ec_val);
     double* s_t_w = (double*)(lraw + T.o_t_w);
-    unsigned* s_e_ptr = (unsigned*)(lraw + T.o_e_ptr);
+    int* s_lev = (int*)(lraw + T.o_lev);
     int* s_meta = (int*)(lraw + T.o_meta);
     unsigned short* s_csr_col = (unsigned short*)(lraw + T.o_csr_col);
     unsigned short* s_csr_ptr = (unsigned short*)(lraw + T.o_csr_ptr);
     unsigned short* s_csr_len = (unsigned short*)(lraw + T.o_csr_len);
     unsigned short* s_ec_row = (unsigned short*)(lraw + T.o_ec_row);
-    unsigned short* s_colmap = (unsigned short*)(lraw + T.o_colmap);
-    unsigned short* s_e_dst = (unsigned short*)(lraw + T.o_e_dst);
-    unsigned short* s_t_col = (unsigned short*)(lraw + T.o_t_col);
+    unsigned* s_colmap = (unsigned*)(lraw + T.o_colmap);
+    unsigned* s_t_cd = (unsigned*)(lraw + T.o_t_cd);
     const int nth = blockDim.x;
     for (int i = tid; i < T.nnz; i += nth) {
         s_csr_val[i] = T.csr_val[i]; s_csr_col[i] = T.csr_col[i];
@@ -500,14 +716,13 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
     for (int i = tid; i < G::MPL; i += nth) { s_csr_ptr[i] = T.csr_ptr[i]; s_csr_len[i] = T.csr_len[i]; }
     for (int i = tid; i < T.ctot * 64; i += nth) { s_ec_val[i] = T.ec_val[i]; s_ec_row[i] = T.ec_row[i]; }
     for (int i = tid; i < 64 * NQ; i += nth) s_colmap[i] = T.colmap[i];
-    for (int i = tid; i < T.n_term; i += nth) { s_t_w[i] = T.t_w[i]; s_t_col[i] = T.t_col[i]; }
-    for (int i = tid; i < T.n_ent; i += nth) s_e_dst[i] = T.e_dst[i];
-    for (int i = tid; i <= T.n_ent; i += nth) s_e_ptr[i] = T.e_ptr[i];
+    for (int i = tid; i < T.n_term; i += nth) { s_t_w[i] = T.t_w[i]; s_t_cd[i] = T.t_cd[i]; }
+    for (int i = tid; i <= T.n_lev; i += nth) s_lev[i] = T.lev[i];
     for (int i = tid; i < META_N; i += nth) s_meta[i] = T.meta[i];
     __syncthreads();
     w.csr_val = s_csr_val; w.csr_col = s_csr_col; w.csr_ptr = s_csr_ptr; w.csr_len = s_csr_len;
     w.ec_val = s_ec_val; w.ec_row = s_ec_row; w.colmap = s_colmap;
-    w.e_ptr = s_e_ptr; w.e_dst = s_e_dst; w.t_w = s_t_w; w.t_col = s_t_col; w.meta = s_meta;
+    w.t_w = s_t_w; w.t_cd = s_t_cd; w.lev = s_lev; w.meta = s_meta;
     wreg_carve(w, (double*)(lraw + T.o_wave) + (size_t)(tid >> 6) * T.wave_doubles, tid);
     w.m = T.m; w.n = T.n; w.rmax = T.rmax;
 }
@@ -516,26 +731,24 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
 // refinement of oracle newton_dy):  M dy = A(d t) - rho,  dx = d (t - A'dy),  then  e = rho - A dx;  M eta = e;
 // dx += d A'eta;  dy -= eta  while max|e| > etol, at most max_refine times.  The first solve is written as pass 0 of that
 // loop so that the kernel holds ONE copy of the (fully unrolled) block substitution.
-// In: t (per column, parked in the stage), rho (per row), um = A(d t) - rho in LDS, the factor in w.U / w.wl_().
+// In: t (per column, parked in the stage), d in vd_(), rho (per row), um = A(d t) - rho in LDS, the factor in w.P / w.wl_().
 // Out: dy (per row), dx, wv = A'dy.  Returns the refinement passes used; `bad` reports a non-finite dy.
 template <int MB, int NQ>
-__device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const double (&x)[NQ], const double (&z)[NQ],
-                                            const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
+__device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
                                             const double (&rho)[WGeo<MB>::MR], double etol, int max_refine,
                                             double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ], bool& bad STAMP_ARGS) {
     constexpr int MR = WGeo<MB>::MR, MP = WGeo<MB>::MP;
-    const int lane = w.lane;
+    const int& lane = w.lane;
     double* vx = w.stage_();
-    double d[NQ];
-#pragma unroll
-    for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
     int pass = 0;
     bad = false;
     for (;;) {
         w.solve();
         STAMP(7)
-        double w2[NQ];
+        double w2[NQ], d[NQ];
         w.At(w.um_(), w2);
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) d[qq] = w.vd_()[lane + 64 * qq];      // d = x/z (0 in padded positions), still there from gram()
         if (pass == 0) {
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
@@ -592,15 +805,14 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     WReg<MB, NQ> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
-    const int lane = w.lane;
+    const int& lane = w.lane;
     const int m = w.m, n = w.n;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
     const double nm = (double)(n + m);
     double* vx = w.stage_();
     bool okc[NQ], okr[MR];
-    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
+    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
 
@@ -614,13 +826,14 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     while (lp < B) {
         double x[NQ], z[NQ];
         double c2 = 0.0;
+        const __amdgpu_buffer_rsrc_t rc = row_rsrc(cg + lp * n, n), rx = row_rsrc(xg + lp * n, n), rz = row_rsrc(zg ? zg + lp * n : nullptr, n);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = jc[qq];
-            const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
+            const unsigned jo = w.coff(qq);
+            const double cj = buf_ld(rc, jo);
             c2 = fma(cj, cj, c2);
-            x[qq] = (warm && okc[qq]) ? xg[lp * n + j] : 1.0;
-            z[qq] = (warm && okc[qq]) ? zg[lp * n + j] : 1.0;
+            x[qq] = (warm && okc[qq]) ? buf_ld(rx, jo) : 1.0;
+            z[qq] = (warm && okc[qq]) ? buf_ld(rz, jo) : 1.0;
         }
         double b2 = 0.0;
 #pragma unroll
@@ -645,7 +858,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             // ---- sigma, gamma, objectives (primal_normal.cl:96-120, 245-248) ----
             double v[NQ], cq[NQ];
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) cq[qq] = okc[qq] ? cg[lp * n + jc[qq]] : 0.0;   // in flight (vmcnt) while A'y runs on LDS
+            for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
             w.At(w.ys_(), v);
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
@@ -664,6 +877,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
             const double norms = uni(sqrt(s2));
             const double mu = uni(o.delta * gam / nm);
+            STAMP(10)
             // ---- d, t; rho = b - A x (primal_normal.cl:50-74) ----
             double t[NQ];
 #pragma unroll
@@ -690,6 +904,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             else if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; running = false; }
             else if (normr > 10.0 * normr0 && normr > PYCLLP_GROWTH_FLOOR * tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; running = false; }
             else if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; running = false; }
+            STAMP(11)
             if (running) {
                 // ---- rhs = A (d t) - rho, diag(M) ----
                 wave_lds_sync();
@@ -709,17 +924,26 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 wave_lds_sync();
                 STAMP(0)
                 // ---- M = A diag(d) A' into registers, t parked in the stage, factor ----
-                w.gram();
+                w.gram(Md);
                 STAMP(1)
+                // t, x and (where it fits in front of the tile) z wait in the stage while factor and solve have the registers
 #pragma unroll
-                for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
-                const bool viol = w.template factor<false>(beta2, o.pivot_floor, [&](auto Kc, double* tile) {
-                    w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
+                for (int qq = 0; qq < NQ; qq++) {
+                    w.stage_()[lane + 64 * qq] = t[qq];
+                    w.stage_()[64 * NQ + lane + 64 * qq] = x[qq];
+                    w.stage_()[128 * NQ + lane + 64 * qq] = z[qq];
+                }
+                const bool viol = w.template factor<false>(beta2, o.pivot_floor STAMP_PASS);
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) {
+                    x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                    z[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
+                }
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
                     double dy[MR], wv[NQ], dx[NQ];
                     bool bad;
-                    (void)newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
+                    (void)newton_solve(w, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
                     if (bad) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
                     else {
                         // ---- step (primal_normal.cl:158-198) ----
@@ -754,10 +978,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             if (lane == 0) { const int k = atomicAdd(defer, 1); defer[1 + k] = (int)lp; status[lp] = -1; }
         } else {
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) {
-                const int j = jc[qq];
-                if (okc[qq]) { xg[lp * n + j] = x[qq]; if (zg) zg[lp * n + j] = z[qq]; }
-            }
+            for (int qq = 0; qq < NQ; qq++) { const unsigned jo = w.coff(qq); buf_st(rx, jo, x[qq]); buf_st(rz, jo, z[qq]); }     // padded positions and a null z: dropped
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
@@ -795,16 +1016,15 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     WReg<MB, NQ> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
-    const int lane = w.lane;
+    const int& lane = w.lane;
     const int m = w.m, n = w.n;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
     const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
     double* vx = w.stage_();
     double* pv = w.flr_();          // p = M^-1 (A(d c) - b): the floor vector is dead once the factor exists
     bool okc[NQ], okr[MR];
-    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
+    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
 
@@ -818,13 +1038,14 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     while (lp < B) {
         double x[NQ], z[NQ];
         double c2 = 0.0, g0 = 0.0;
+        const __amdgpu_buffer_rsrc_t rc = row_rsrc(cg + lp * n, n), rx = row_rsrc(xg + lp * n, n), rz = row_rsrc(zg ? zg + lp * n : nullptr, n);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = jc[qq];
-            const double cj = okc[qq] ? cg[lp * n + j] : 0.0;
+            const unsigned jo = w.coff(qq);
+            const double cj = buf_ld(rc, jo);
             c2 = fma(cj, cj, c2);
-            x[qq] = (warm && okc[qq]) ? xg[lp * n + j] : 1.0;
-            z[qq] = (warm && okc[qq]) ? zg[lp * n + j] : 1.0;
+            x[qq] = (warm && okc[qq]) ? buf_ld(rx, jo) : 1.0;
+            z[qq] = (warm && okc[qq]) ? buf_ld(rz, jo) : 1.0;
             g0 += okc[qq] ? x[qq] * z[qq] : 0.0;
         }
         double b2 = 0.0;
@@ -851,7 +1072,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             // ---- sigma = c tau - A'y + z, gamma, objectives ----
             double v[NQ], cq[NQ], sg[NQ];
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) cq[qq] = okc[qq] ? cg[lp * n + jc[qq]] : 0.0;   // in flight (vmcnt) while A'y runs on LDS
+            for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
             w.At(w.ys_(), v);
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
@@ -929,12 +1150,11 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 const double beta2 = uni(wmax(bmax));
                 wave_lds_sync();
                 STAMP(0)
-                w.gram();
+                w.gram(Md);
                 STAMP(1)
 #pragma unroll
                 for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
-                const bool viol = w.template factor<true>(beta2, 0.0, [&](auto Kc, double* tile) {
-                    w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
+                const bool viol = w.template factor<true>(beta2, 0.0 STAMP_PASS);
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
                     // ---- one loop around the ONE copy of the block substitution: pass 0 solves for p, pass 1 for q and
@@ -1056,10 +1276,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             // optimal (and iteration-limit) points leave the homogeneous scaling (hsd.c:266-273); certificates stay
             const double rt = (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT) ? 1.0 / tau : 1.0;
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) {
-                const int j = jc[qq];
-                if (okc[qq]) { xg[lp * n + j] = x[qq] * rt; if (zg) zg[lp * n + j] = z[qq] * rt; }
-            }
+            for (int qq = 0; qq < NQ; qq++) { const unsigned jo = w.coff(qq); buf_st(rx, jo, x[qq] * rt); buf_st(rz, jo, z[qq] * rt); }   // padded positions, null z: dropped
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
@@ -1095,12 +1312,11 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
     WReg<MB, NQ> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
-    const int lane = w.lane, m = w.m, n = w.n;
+    const int& lane = w.lane; const int m = w.m, n = w.n;
     double* vx = w.stage_();
     bool okc[NQ], okr[MR];
-    int jc[NQ];       // the column that lives at position lane + 64 q of the N-vectors
 #pragma unroll
-    for (int qq = 0; qq < NQ; qq++) { okc[qq] = lane + 64 * qq < n; jc[qq] = w.colmap[lane + 64 * qq]; }
+    for (int qq = 0; qq < NQ; qq++) okc[qq] = lane + 64 * qq < n;
 #pragma unroll
     for (int r2 = 0; r2 < MR; r2++) okr[r2] = lane + 64 * r2 < m;
     long lp;
@@ -1124,10 +1340,11 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
         w.At(w.ys_(), v);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
-            const int j = lane + 64 * qq, jg = jc[qq];
-            x[qq] = okc[qq] ? xg[lp * n + jg] : 1.0;
-            z[qq] = okc[qq] ? zg[lp * n + jg] : 1.0;
-            const double cj = okc[qq] ? cg[lp * n + jg] : 0.0;
+            const int j = lane + 64 * qq;
+            const unsigned jo = w.coff(qq);
+            x[qq] = okc[qq] ? buf_ld(row_rsrc(xg + lp * n, n), jo) : 1.0;
+            z[qq] = okc[qq] ? buf_ld(row_rsrc(zg + lp * n, n), jo) : 1.0;
+            const double cj = buf_ld(row_rsrc(cg + lp * n, n), jo);
             t[qq] = okc[qq] ? cj - v[qq] + mu * fast_rcp(x[qq]) : 0.0;
             vx[j] = okc[qq] ? x[qq] : 0.0;
             w.vd_()[j] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
@@ -1150,17 +1367,16 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
         }
         const double beta2 = wmax(bmax);
         wave_lds_sync();
-        w.gram();
+        w.gram(Md);
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
 #ifdef PYCLLP_PROFILE
         unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0};
 #endif
-        (void)w.template factor<false>(beta2, o.pivot_floor, [&](auto Kc, double* tile) {
-            w.template diag_from_tables<decltype(Kc)::value>(tile, Md); } STAMP_PASS);
+        (void)w.template factor<false>(beta2, o.pivot_floor STAMP_PASS);
         double dy[MR], wv[NQ], dx[NQ];
         bool bad;
-        const int nref = newton_solve(w, x, z, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
+        const int nref = newton_solve(w, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) if (okr[r2]) dyg[lp * m + lane + 64 * r2] = dy[r2];
         if (nrefg && lane == 0) nrefg[lp] = nref;
@@ -1186,7 +1402,7 @@ ldl_solve_wreg_kernel(int n, long B, const double* __restrict__ Ag, const double
     USE_AGPR_FORM();
     const int tid = threadIdx.x;
     wreg_carve(w, (double*)lraw + (size_t)(tid >> 6) * G::WAVE_D(1), tid);
-    const int lane = w.lane, q = w.q, c16 = w.c16;
+    const int &lane = w.lane, &q = w.q, &c16 = w.c16;
     long mat;
     {
         int nxt = 0;
@@ -1210,21 +1426,20 @@ ldl_solve_wreg_kernel(int n, long B, const double* __restrict__ Ag, const double
             });
         });
         for (int i = lane; i < MP; i += 64) w.um_()[i] = (i < n) ? rhs[mat * n + i] : 0.0;
+        // diagonal blocks into their slots: element [row][col], col <= row, of block K at K WL + row (row + 1) / 2 + col
+        static_for<0, MB>([&](auto Kc) {
+            constexpr int K = decltype(Kc)::value;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int il = 4 * r + q, row = 16 * K + il, col = 16 * K + c16;
+                if (c16 <= il) w.wl_()[K * WL + il * (il + 1) / 2 + c16] = (row < n) ? A[(long)row * n + col] : ((row == col) ? 1.0 : 0.0);
+            }
+        });
         wave_lds_sync();
 #ifdef PYCLLP_PROFILE
         unsigned long long t_prev_ = 0, t_acc_[NPHASE] = {0};
 #endif
-        // diagonal blocks come straight from memory when their turn comes: element [row][col], col <= row, of block K
-        (void)w.template factor<false>(1e300, floor_, [&](auto Kc, double* tile) {
-            constexpr int K = decltype(Kc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * K + 4 * r + q, col = 16 * K + c16;
-                double v = 0.0;
-                if (col <= row) v = (row < n) ? A[(long)row * n + col] : ((row == col) ? 1.0 : 0.0);
-                tile[(4 * r + q) * 17 + c16] += v;
-            }
-        } STAMP_PASS);
+        (void)w.template factor<false>(1e300, floor_ STAMP_PASS);
         w.solve();
         for (int i = lane; i < n; i += 64) out[mat * n + i] = w.um_()[i];
         wave_lds_sync();
@@ -1272,8 +1487,6 @@ size_t put(std::vector<char>& host, const std::vector<T>& v) {
     return off;
 }
 
-int nch_host(int MB, int K) { return (MB - 1 - K + HB - 1) / HB; }
-
 typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const double*, double*, double*, double*, double*,
                                 double*, int*, int*, int*, int*, DevOpts, int, hipStream_t);
 typedef hipError_t (*wnewton_fn)(const WregTab&, long, const double*, const double*, const double*, const double*,
@@ -1312,7 +1525,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 struct WVariant { int mb, nq; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_solve_hsd<MB, NQ>, do_newton<MB, NQ> }
 // ordered by cost; the first variant with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(8, 6) };
+const WVariant kWVariants[] = { WVARIANT(8, 4), WVARIANT(8, 6) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace
@@ -1343,8 +1556,8 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     std::vector<int> order(n), posof(n);
     for (int j = 0; j < n; j++) order[j] = j;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cptr[a + 1] - cptr[a] > cptr[b + 1] - cptr[b]; });
-    std::vector<unsigned short> colmap(NP, 0);
-    for (int p = 0; p < n; p++) { colmap[p] = (unsigned short)order[p]; posof[order[p]] = p; }
+    std::vector<unsigned> colmap(NP, PAD_OFF);
+    for (int p = 0; p < n; p++) { colmap[p] = 8u * (unsigned)order[p]; posof[order[p]] = p; }
     // ---- A by rows (column indices = positions), compact ----
     std::vector<double> csr_val(val, val + nnz);
     std::vector<unsigned short> csr_col(nnz), csr_ptr(MPL, 0), csr_len(MPL, 0);
@@ -1372,82 +1585,83 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
             ec_row[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = (unsigned short)crow[e];
         }
     }
-    // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk, then the entries
-    //      inside the diagonal blocks grouped by block ----
+    // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk (HB blocks of the
+    //      linear block order each), then the entries inside the diagonal blocks, addressed relative to the W area ----
     struct Term { int group, dst, colj; double w; };
     std::vector<Term> terms;
-    std::vector<int> chbase(MB + 1, 0);
-    for (int K = 0; K < MB; K++) chbase[K + 1] = chbase[K] + nch_host(MB, K);
-    const int nchunk = chbase[MB];
-    if (nchunk + 1 > 24 || MB + 1 > 24) { delete P; return 1; }
+    const int nblk = MB * (MB - 1) / 2, nchunk = (nblk + HB - 1) / HB;
+    if (nchunk + 2 > META_N - META_SEG) { delete P; return 1; }
     for (int j = 0; j < n; j++)
         for (int a = cptr[j]; a < cptr[j + 1]; a++)
             for (int b2 = cptr[j]; b2 < a; b2++) {
                 const int i = crow[a], k = crow[b2];   // rows ascend inside a column: i > k
-                const int K = k / 16, I = i / 16;
-                if (I == K) {          // diagonal block K: element [i%16][k%16] of the stride-17 tile
-                    terms.push_back({nchunk + K, (i % 16) * 17 + (k % 16), posof[j], csc_val[a] * csc_val[b2]});
-                } else {               // block (K, I) of U: element [k%16][i%16], block (I-K-1) % HB of its chunk
-                    const int ch = (I - K - 1) / HB, bi = (I - K - 1) % HB;
-                    terms.push_back({chbase[K] + ch, bi * 256 + (k % 16) * 16 + (i % 16), posof[j], csc_val[a] * csc_val[b2]});
+                const int K = k / 16, I = i / 16, il = i % 16, kl = k % 16;
+                if (I == K) {          // diagonal block K: element [il][kl] of the packed lower triangle in slot K
+                    terms.push_back({nchunk, K * WL + il * (il + 1) / 2 + kl, posof[j], csc_val[a] * csc_val[b2]});
+                } else {               // block (K, I) of U: element [kl][il] of block bix % HB of chunk bix / HB
+                    const int bx = K * MB - K * (K + 1) / 2 + (I - K - 1);
+                    terms.push_back({bx / HB, (bx % HB) * 256 + kl * 16 + il, posof[j], csc_val[a] * csc_val[b2]});
                 }
                 if (terms.size() > ((size_t)1 << 22)) { delete P; return 1; }
             }
+    // level of a term = its rank inside its entry, in column order (the order a per-entry loop would add them in)
     std::stable_sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) {
         return a.group != b.group ? a.group < b.group : a.dst < b.dst; });
-    std::vector<unsigned> e_ptr; std::vector<unsigned short> e_dst, t_col(terms.size());
+    std::vector<int> level(terms.size(), 0);
+    for (size_t t = 1; t < terms.size(); t++)
+        if (terms[t].group == terms[t - 1].group && terms[t].dst == terms[t - 1].dst) level[t] = level[t - 1] + 1;
+    std::vector<size_t> ord(terms.size());
+    for (size_t t = 0; t < ord.size(); t++) ord[t] = t;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        return terms[a].group != terms[b].group ? terms[a].group < terms[b].group : level[a] < level[b]; });
+    const int ngroup = nchunk + 1;
     std::vector<double> t_w(terms.size());
-    const int ngroup = nchunk + MB;
-    std::vector<int> seg(ngroup + 1, 0);
-    for (size_t t = 0; t < terms.size(); t++) {
-        if (t == 0 || terms[t].group != terms[t - 1].group || terms[t].dst != terms[t - 1].dst) {
-            e_ptr.push_back((unsigned)t); e_dst.push_back((unsigned short)terms[t].dst);
-            seg[terms[t].group + 1] = (int)e_dst.size();
-        }
-        t_col[t] = (unsigned short)terms[t].colj; t_w[t] = terms[t].w;
+    std::vector<unsigned> t_cd(terms.size());
+    std::vector<int> lev(1, 0), gl(ngroup + 1, 0);
+    for (size_t u = 0; u < ord.size(); u++) {
+        const Term& tm = terms[ord[u]];
+        t_w[u] = tm.w; t_cd[u] = (unsigned)tm.colj | ((unsigned)tm.dst << 16);
+        const bool last = u + 1 == ord.size() || terms[ord[u + 1]].group != tm.group || level[ord[u + 1]] != level[ord[u]];
+        if (last) { lev.push_back((int)u + 1); gl[tm.group + 1] = (int)lev.size() - 1; }
     }
-    e_ptr.push_back((unsigned)terms.size());
-    for (int i = 1; i <= ngroup; i++) seg[i] = std::max(seg[i], seg[i - 1]);
-    for (int i = 0; i <= nchunk; i++) T.meta[META_SEG + i] = seg[i];
-    for (int K = 0; K <= MB; K++) T.meta[META_DSEG + K] = seg[nchunk + K];
-    T.n_ent = (int)e_dst.size(); T.n_term = (int)terms.size();
-    if (t_w.empty()) { t_w.push_back(0.0); t_col.push_back(0); }
-    if (e_dst.empty()) e_dst.push_back(0);
+    for (int g = 1; g <= ngroup; g++) gl[g] = std::max(gl[g], gl[g - 1]);
+    for (int g = 0; g <= ngroup; g++) T.meta[META_SEG + g] = gl[g];
+    T.n_lev = (int)lev.size() - 1; T.n_term = (int)terms.size();
+    if (t_w.empty()) { t_w.push_back(0.0); t_cd.push_back(0); }
     // ---- LDS plan ----
     size_t off = 0;
     auto take = [&](size_t bytes) { off = (off + 15) & ~(size_t)15; const size_t o_ = off; off += bytes; return (int)o_; };
     T.o_csr_val = take(sizeof(double) * csr_val.size());
     T.o_ec_val = take(sizeof(double) * ec_val.size());
     T.o_t_w = take(sizeof(double) * t_w.size());
-    T.wave_doubles = STAGE_D + 64 * NQ + 6 * MP + MB * WL;
+    T.wave_doubles = stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL;
     T.o_wave = take(sizeof(double) * 4 * (size_t)T.wave_doubles);
-    T.o_e_ptr = take(sizeof(unsigned) * e_ptr.size());
+    T.o_lev = take(sizeof(int) * lev.size());
+    T.o_t_cd = take(sizeof(unsigned) * t_cd.size());
+    T.o_colmap = take(sizeof(unsigned) * colmap.size());
     T.o_meta = take(sizeof(int) * META_N);
     T.o_csr_col = take(sizeof(unsigned short) * csr_col.size());
     T.o_csr_ptr = take(sizeof(unsigned short) * csr_ptr.size());
     T.o_csr_len = take(sizeof(unsigned short) * csr_len.size());
     T.o_ec_row = take(sizeof(unsigned short) * ec_row.size());
-    T.o_colmap = take(sizeof(unsigned short) * colmap.size());
-    T.o_e_dst = take(sizeof(unsigned short) * e_dst.size());
-    T.o_t_col = take(sizeof(unsigned short) * t_col.size());
     T.lds_bytes = (int)((off + 15) & ~(size_t)15);
     if (T.lds_bytes > max_lds) { delete P; return 1; }
     // ---- device copies ----
     std::vector<char> host;
-    const size_t a1 = put(host, csr_val), a2 = put(host, ec_val), a3 = put(host, t_w), a4 = put(host, e_ptr),
+    const size_t a1 = put(host, csr_val), a2 = put(host, ec_val), a3 = put(host, t_w), a4 = put(host, lev),
                  a5 = put(host, csr_col), a6 = put(host, csr_ptr), a7 = put(host, csr_len), a8 = put(host, ec_row),
-                 a9 = put(host, colmap), a11 = put(host, e_dst), a12 = put(host, t_col);
+                 a9 = put(host, colmap), a11 = put(host, t_cd);
     hipError_t e = hipMalloc(&P->dev_blob, host.size());
     if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { if (P->dev_blob) (void)hipFree(P->dev_blob); delete P; return 1000 + (int)e; }
     char* db = (char*)P->dev_blob;
     T.csr_val = (const double*)(db + a1); T.ec_val = (const double*)(db + a2); T.t_w = (const double*)(db + a3);
-    T.e_ptr = (const unsigned*)(db + a4);
+    T.lev = (const int*)(db + a4);
     T.csr_col = (const unsigned short*)(db + a5); T.csr_ptr = (const unsigned short*)(db + a6);
     T.csr_len = (const unsigned short*)(db + a7); T.ec_row = (const unsigned short*)(db + a8);
-    T.colmap = (const unsigned short*)(db + a9);
-    T.e_dst = (const unsigned short*)(db + a11); T.t_col = (const unsigned short*)(db + a12);
+    T.colmap = (const unsigned*)(db + a9);
+    T.t_cd = (const unsigned*)(db + a11);
     P->mb = MB; P->nq = NQ;
     *out = P;
     return 0;

@@ -71,7 +71,7 @@ struct DevOpts {
 
 // In-kernel phase stamps (diagnostic build only; the shipped library has no stamp executing).
 #ifdef PYCLLP_PROFILE
-#define NPHASE 10
+#define NPHASE 12
 #ifdef PYCLLP_PROFILE_LITE   // fewer live counters: the full set costs registers and distorts a kernel at the VGPR limit
 #define PHASE_MAP(i) ((i) <= 1 ? 0 : (i) == 2 ? 2 : (i) <= 4 ? 4 : (i) == 5 ? 5 : (i) <= 7 ? 6 : 8)
 #else

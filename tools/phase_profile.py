@@ -10,7 +10,7 @@ from pycllp_amd import problems, _native
 from pycllp_amd.lp import EqualityLP, SparseMatrix
 from pycllp_amd.solvers.hip import HipDensePrimalNormalSolver
 
-NPHASE = 10
+NPHASE = 12
 names = ["0 elementwise+reductions", "1 d,t,kbuf", "2 gram(MFMA)+Ax", "3 slab->rows,beta", "4 factor LDL", "5 fwd/back",
          "6 A'dy", "7 A dx + maxe (refine check)", "8 stop tests + step (+store)", "9 load LP"]
 LPW = 2  # LPs per wave in the group kernel at m<=32 (4 at m<=16)
@@ -37,6 +37,6 @@ print("kernel %.2f ms (stamped build), %d waves, LP-iterations per wave %.1f" % 
 print("(cycles below are per LP-iteration, i.e. wave cycles divided by the LP-iterations the wave served)")
 print("cycles per wave: mean %.3g  min %.3g  max %.3g" % (tot.mean(), tot.min(), tot.max()))
 per_it = p.sum(0) / (iters.sum() + B)
-for i in range(NPHASE):
+for i in range(min(NPHASE, len(names))):
     print("%-34s %6.1f%%   %8.0f cycles per LP-iteration" % (names[i], 100 * p[:, i].sum() / p.sum(), per_it[i]))
 print("total %.0f cycles per LP-iteration per wave" % per_it.sum())

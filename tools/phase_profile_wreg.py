@@ -6,10 +6,10 @@ import numpy as np, torch
 from pycllp_amd import problems, _native
 from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry
-NPHASE = 10
+NPHASE = 12
 names = ["0 A'y, norms, d, t, A x, tests, A(dt), diag(M)", "1 Gram scatter + block loads", "2 LDL': Schur MFMA of the diagonal block -> tile",
          "3 LDL': original diagonal block from the tables -> tile", "4 LDL': tile -> rows, 16-step pivot chain", "5 LDL': W = L_KK^-1, panel (MFMA)", "6 LDL': trailing update (MFMA)",
-         "7 block substitution (solve)", "8 A'dy, dx, A dx, refinement test", "9 step, load/store LP"]
+         "7 block substitution (solve)", "8 A'dy, dx, A dx, refinement test", "9 step, load/store LP", "10 (of 0) A'y, sigma, gamma, objectives", "11 (of 0) d, t, A x, rho, stop tests"]
 m, n, B = 128, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 A, b, c = problems.random_sparse_arrays(m, n, B, density=0.025, seed=0)
 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
