@@ -143,11 +143,11 @@ __device__ __forceinline__ double uni(double v) {
 // whole-wave reductions: DPP inside the rows, then the four row results through SGPRs (wave-uniform result)
 __device__ __forceinline__ double wsum(double v) {
     v = row_sum(v);
-    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+    return uni((readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48)));
 }
 __device__ __forceinline__ double wmax(double v) {
     v = row_max(v);
-    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+    return uni(fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48))));
 }
 
 // ---- per-LP vectors in global memory through buffer descriptors ------------------------------------------------
@@ -502,11 +502,17 @@ struct WReg {
     }
 
     // W_K element [row 4s + q][column c16] -- the TRANSPOSED operand layout -- from the packed copy in LDS
+    // (the strictly-lower entries come from the slot; the slot's spare doubles [136, 144) hold what factor() stored for the
+    // positions on and above the diagonal: 1 on it, 0 above -- so the read is one unconditional load at offset woff[s])
     template <int K>
-    __device__ __forceinline__ double w_elemT(int s) const {
-        const int row = 4 * s + q;
-        const double v = wl_()[K * WL + ((c16 < row) ? row * (row - 1) / 2 + c16 : 0)];
-        return (c16 < row) ? v : ((c16 == row) ? 1.0 : 0.0);
+    __device__ __forceinline__ double w_elemT(int s, const int (&woff)[4]) const { return wl_()[K * WL + woff[s]]; }
+    __device__ __forceinline__ void w_offsets(int (&woff)[4]) const {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int row = 4 * s + q;
+            woff[s] = (c16 < row) ? row * (row - 1) / 2 + c16 : ((c16 == row) ? 136 : 137);
+            asm volatile("" : "+v"(woff[s]));
+        }
     }
 
     // Blocked LDL' of the matrix whose off-diagonal blocks are parked in P and whose diagonal blocks sit in the slots of
@@ -518,20 +524,34 @@ struct WReg {
         // guard verdict, kept as a per-lane integer that every test is folded into AT ONCE (asm pin): left as a boolean the
         // compiler sinks the 16 + 112 compares to the end of the sweep and keeps their operands alive until then
         int viol = 0;
+        double ymax = 0.0;
         double* tile = stage_() + TILE_OFF;
         static_for<0, MB>([&](auto Kc) {
             constexpr int K = decltype(Kc)::value;
             pin();
             // ---- diagonal block K, left-looking: Schur update -sum_{K'<K} (D U_K'K)' U_K'K on the matrix cores ----
-            double4_t sch = {0.0, 0.0, 0.0, 0.0};
-            static_for<0, K>([&](auto Kp) {
-                constexpr int K2 = decltype(Kp)::value;
+            //      1/D of the pivots 4t + q, t < 4K, in one or two round trips; two accumulators, so that consecutive MFMAs do
+            //      not wait for each other
+            double4_t sch = {0.0, 0.0, 0.0, 0.0}, sch1 = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (K > 0) {
+                static_for<0, (K + 3) / 4>([&](auto Hc) {
+                    constexpr int H = decltype(Hc)::value;          // block rows 4H .. 4H + 3 (< K)
+                    double rdk[16];
+                    lds_run16<512 * H, 32>(lds_addr(rdv_() + q), rdk);
+                    static_for<4 * H, (4 * H + 4 < K ? 4 * H + 4 : K)>([&](auto Kp) {
+                        constexpr int K2 = decltype(Kp)::value;
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const double y = unpark(P[G::bix(K2, K)], s);
-                    sch = __builtin_amdgcn_mfma_f64_16x16x4f64(-(y * rdv_()[16 * K2 + 4 * s + q]), y, sch, 0, 0, 0);
-                }
-            });
+                        for (int s = 0; s < 4; s++) {
+                            const double y = unpark(P[G::bix(K2, K)], s);
+                            const double ny = -(y * rdk[4 * (K2 - 4 * H) + s]);
+                            if (s & 1) sch1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ny, y, sch1, 0, 0, 0);
+                            else sch = __builtin_amdgcn_mfma_f64_16x16x4f64(ny, y, sch, 0, 0, 0);
+                        }
+                    });
+                });
+#pragma unroll
+                for (int r = 0; r < 4; r++) sch[r] += sch1[r];
+            }
             // accumulator layout -> tile, + original block -> lane = row (each 16-lane row of the wave a redundant copy)
 #pragma unroll
             for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = sch[r];
@@ -577,9 +597,11 @@ struct WReg {
                 constexpr int j = decltype(jc)::value;
                 winv_step<j>(Ws, Ld[j]);
             });
-            // (entries on and above the diagonal go to the spare doubles [136, 144) of the slot: one store each, no branch)
+            // (entries on and above the diagonal go to spare doubles of the slot: one store each, no branch; [136] and [137]
+            // get the constants 1 and 0 that solve() reads for the diagonal and the upper triangle of W)
 #pragma unroll
-            for (int s = 0; s < 4; s++) wl_()[K * WL + ((4 * s + q < c16) ? c16 * (c16 - 1) / 2 + 4 * s + q : 136 + s)] = Ws[s];
+            for (int s = 0; s < 4; s++) wl_()[K * WL + ((4 * s + q < c16) ? c16 * (c16 - 1) / 2 + 4 * s + q : 138 + s)] = Ws[s];
+            if (lane < 2) wl_()[K * WL + 136 + lane] = (lane == 0) ? 1.0 : 0.0;
             // 1/D in the row form of the accumulator layout (register r <-> pivot 4r + q), back from LDS
             wave_lds_sync();
             double rDr[4];
@@ -595,8 +617,8 @@ struct WReg {
                 for (int s = 0; s < 4; s++)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ws[s], (K == 0) ? unpark(P[G::bix(K, I)], s) : U[G::bix(K, I)][s], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) viol |= (acc[r] * acc[r] * rDr[r] > beta2) ? 1 : 0;      // Y^2 / D > beta^2
-                asm volatile("" : "+v"(viol));
+                for (int r = 0; r < 4; r++) ymax = fmax(ymax, acc[r] * acc[r] * rDr[r]);      // Y^2 / D, compared with beta^2 once, at the end
+                asm volatile("" : "+v"(ymax));
                 park(P[G::bix(K, I)], acc);
             });
             STAMP(5)
@@ -625,7 +647,7 @@ struct WReg {
             __builtin_amdgcn_sched_barrier(0);   // one panel at a time: nothing of panel K+1 is hoisted above this line
         });
         wave_lds_sync();
-        return __any(viol != 0);
+        return __any(viol != 0 || ymax > beta2);
     }
 
     // um <- (L D L')^-1 um.  Vectors of a 16-row block appear in two forms: "column form" (lane (c16, q) holds element
@@ -637,7 +659,9 @@ struct WReg {
     // Forward substitution is column oriented (t_K, once known, is folded into the partial sums of all later block rows
     // and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
     __device__ __forceinline__ void solve() {
-        pin();          // once: the packed-triangle indices of w_elemT (an integer multiply each) are worth keeping for the 16 stages
+        pin();          // once: the packed-triangle offsets of w_elemT (an integer multiply each) are kept for the 16 stages
+        int woff[4];
+        w_offsets(woff);
         double p[MB];
 #pragma unroll
         for (int I = 0; I < MB; I++) p[I] = 0.0;
@@ -648,7 +672,7 @@ struct WReg {
             if constexpr (I > 0) rC -= quad_sum(p[I]);
             double tR[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) tR[s] = row_sum(w_elemT<I>(s) * rC);
+            for (int s = 0; s < 4; s++) tR[s] = row_sum(w_elemT<I>(s, woff) * rC);
 #pragma unroll
             for (int s = 0; s < 4; s++) if (c16 == 0) um_()[16 * I + 4 * s + q] = tR[s];
             if constexpr (I + 1 < MB) {
@@ -677,7 +701,7 @@ struct WReg {
             for (int r = 0; r < 4; r++) {
                 double v = um_()[16 * K + 4 * r + q];
                 if constexpr (K < MB - 1) v -= row_sum(pr[r]);
-                px = fma(w_elemT<K>(r), v * rdv_()[16 * K + 4 * r + q], px);
+                px = fma(w_elemT<K>(r, woff), v * rdv_()[16 * K + 4 * r + q], px);
             }
             xCL[K] = quad_sum(px);
         });
@@ -732,11 +756,14 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
 // dx += d A'eta;  dy -= eta  while max|e| > etol, at most max_refine times.  The first solve is written as pass 0 of that
 // loop so that the kernel holds ONE copy of the (fully unrolled) block substitution.
 // In: t (per column, parked in the stage), d in vd_(), rho (per row), um = A(d t) - rho in LDS, the factor in w.P / w.wl_().
-// Out: dy (per row), dx, wv = A'dy.  Returns the refinement passes used; `bad` reports a non-finite dy.
-template <int MB, int NQ>
+// TCV: the caller has parked x and z in the stage (at NP, 2 NP) and cv = c - A'y in vd_() in place of d; t = cv + mu / x and
+// d = x / z are formed here (the same expressions the caller used for the right-hand side).
+// Out: dy (per row), dx, wv = A'dy, e = rho - A dx.  Returns the refinement passes used; `bad` reports a non-finite dy.
+template <bool TCV, int MB, int NQ>
 __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
-                                            const double (&rho)[WGeo<MB>::MR], double etol, int max_refine,
-                                            double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ], bool& bad STAMP_ARGS) {
+                                            const double (&rho)[WGeo<MB>::MR], double etol, int max_refine, double mu,
+                                            double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ],
+                                            double (&e)[WGeo<MB>::MR], bool& bad STAMP_ARGS) {
     constexpr int MR = WGeo<MB>::MR, MP = WGeo<MB>::MP;
     const int& lane = w.lane;
     double* vx = w.stage_();
@@ -747,12 +774,22 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[N
         STAMP(7)
         double w2[NQ], d[NQ];
         w.At(w.um_(), w2);
+        double xq[NQ];
 #pragma unroll
-        for (int qq = 0; qq < NQ; qq++) d[qq] = w.vd_()[lane + 64 * qq];      // d = x/z (0 in padded positions), still there from gram()
+        for (int qq = 0; qq < NQ; qq++) {
+            if (TCV) {
+                xq[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                d[qq] = okc[qq] ? xq[qq] * fast_rcp(w.stage_()[128 * NQ + lane + 64 * qq]) : 0.0;
+            } else {
+                d[qq] = w.vd_()[lane + 64 * qq];      // d = x/z (0 in padded positions), still there from gram()
+            }
+        }
         if (pass == 0) {
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                const double tq = w.stage_()[lane + 64 * qq];       // t, parked there by the caller
+                double tq;
+                if (TCV) tq = okc[qq] ? w.vd_()[lane + 64 * qq] + mu * fast_rcp(xq[qq]) : 0.0;
+                else tq = w.stage_()[lane + 64 * qq];       // t, parked there by the caller
                 wv[qq] = w2[qq];
                 dx[qq] = (tq - w2[qq]) * d[qq];
             }
@@ -771,7 +808,7 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[N
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = okc[qq] ? dx[qq] : 0.0;
         wave_lds_sync();
-        double Adx[MR], e[MR], dummy[MR], me = 0.0;
+        double Adx[MR], dummy[MR], me = 0.0;
         w.template Arow<false>(vx, Adx, dummy);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) {
@@ -853,65 +890,90 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         double normr0 = 1e300, norms0 = 1e300, po = 0.0, du = 0.0;
         int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
         bool running = true;
+        // The residuals cv = c - A'y and rho = b - A x are CARRIED from iteration to iteration (cv -= theta A'dy,
+        // rho -= theta A dx: both products exist anyway, from the Newton step and its refinement test) and recomputed from
+        // the point itself only at the start and when the carried values pass the optimality test -- the verdict is then
+        // taken again on the exact ones (as the dense group kernel does for rho), and the iteration goes on if it fails.
+        // x, z and cv cross the loop's back edge IN LDS (the slots where they wait during factor and solve anyway), not in
+        // registers: 36 loop-carried registers through this loop's control flow end up in scratch
+        double rho[MR];
+        bool refresh = true, fresh = false;
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) {
+            w.stage_()[64 * NQ + lane + 64 * qq] = x[qq];
+            w.stage_()[128 * NQ + lane + 64 * qq] = z[qq];
+        }
+        wave_lds_sync();
 
         while (running) {
-            // ---- sigma, gamma, objectives (primal_normal.cl:96-120, 245-248) ----
-            double v[NQ], cq[NQ];
+            double x[NQ], z[NQ], cv[NQ];
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
-            w.At(w.ys_(), v);
+            for (int qq = 0; qq < NQ; qq++) {
+                x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                z[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
+                cv[qq] = w.vd_()[lane + 64 * qq];       // (not yet there in the first pass: refresh sets it)
+            }
+            wave_lds_sync();
+            if (refresh) {
+                double v[NQ], cq[NQ], Ax[MR], dm[MR];
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
+                w.At(w.ys_(), v);
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) {
+                    cv[qq] = okc[qq] ? cq[qq] - v[qq] : 0.0;
+                    vx[lane + 64 * qq] = okc[qq] ? x[qq] : 0.0;
+                }
+                wave_lds_sync();
+                w.template Arow<false>(vx, Ax, dm);
+#pragma unroll
+                for (int r2 = 0; r2 < MR; r2++) rho[r2] = okr[r2] ? w.bs_()[lane + 64 * r2] - Ax[r2] : 0.0;
+                wave_lds_sync();
+                refresh = false; fresh = true;
+            }
+            // ---- sigma, gamma, objectives (primal_normal.cl:96-120, 245-248); c'x = cv'x + y'(b - rho) ----
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
-                const double sg = okc[qq] ? cq[qq] - v[qq] + z[qq] : 0.0;
+                const double sg = okc[qq] ? cv[qq] + z[qq] : 0.0;
                 s2 = fma(sg, sg, s2);
                 gam += okc[qq] ? x[qq] * z[qq] : 0.0;
-                pp += cq[qq] * (okc[qq] ? x[qq] : 0.0);
+                pp += okc[qq] ? cv[qq] * x[qq] : 0.0;
             }
-            double dd = 0.0;
+            double dd = 0.0, r2s = 0.0;
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                dd += (i < MP) ? w.bs_()[i] * w.ys_()[i] : 0.0;
+                const double bi = (i < MP) ? w.bs_()[i] : 0.0, yi = (i < MP) ? w.ys_()[i] : 0.0;
+                dd = fma(bi, yi, dd);
+                pp = fma(yi, bi - rho[r2], pp);
+                r2s = fma(rho[r2], rho[r2], r2s);
             }
             s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
             const double norms = uni(sqrt(s2));
+            const double normr = uni(sqrt(wsum(r2s)));
             const double mu = uni(o.delta * gam / nm);
             STAMP(10)
-            // ---- d, t; rho = b - A x (primal_normal.cl:50-74) ----
-            double t[NQ];
-#pragma unroll
-            for (int qq = 0; qq < NQ; qq++) {
-                const int j = lane + 64 * qq;
-                const double dq = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;      // v_rcp_f64 + 2 Newton steps (<= 2 ulp), as
-                t[qq] = okc[qq] ? cq[qq] - v[qq] + mu * fast_rcp(x[qq]) : 0.0;   // the dense group kernel
-                vx[j] = okc[qq] ? x[qq] : 0.0;
-                w.vd_()[j] = dq;
-            }
-            wave_lds_sync();
-            double rho[MR], Ax[MR], Md[MR];
-            w.template Arow<false>(vx, Ax, Md);
-            double r2s = 0.0;
-#pragma unroll
-            for (int r2 = 0; r2 < MR; r2++) {
-                const int i = lane + 64 * r2;
-                rho[r2] = okr[r2] ? w.bs_()[i] - Ax[r2] : 0.0;
-                r2s = fma(rho[r2], rho[r2], r2s);
-            }
-            const double normr = uni(sqrt(wsum(r2s)));
             // ---- stop tests (primal_normal.cl:256-269; oracle ipm_one_path) ----
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
-            else if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; running = false; }
+            else if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) {
+                if (fresh) { stat = PYCLLP_STATUS_OPTIMAL; running = false; } else refresh = true;
+            }
             else if (normr > 10.0 * normr0 && normr > PYCLLP_GROWTH_FLOOR * tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; running = false; }
             else if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; running = false; }
             STAMP(11)
-            if (running) {
-                // ---- rhs = A (d t) - rho, diag(M) ----
-                wave_lds_sync();
+            if (running && !refresh) {
+                // ---- d, t (primal_normal.cl:50-74); rhs = A (d t) - rho, diag(M) ----
 #pragma unroll
-                for (int qq = 0; qq < NQ; qq++) vx[lane + 64 * qq] = w.vd_()[lane + 64 * qq] * t[qq];
+                for (int qq = 0; qq < NQ; qq++) {
+                    const int j = lane + 64 * qq;
+                    const double dq = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;      // v_rcp_f64 + 2 Newton steps (<= 2 ulp), as
+                    const double tq = okc[qq] ? cv[qq] + mu * fast_rcp(x[qq]) : 0.0;   // the dense group kernel
+                    vx[j] = dq * tq;
+                    w.vd_()[j] = dq;
+                }
                 wave_lds_sync();
-                double Adt[MR];
+                double Adt[MR], Md[MR];
                 w.template Arow<true>(vx, Adt, Md);
                 double bmax = 0.0;
 #pragma unroll
@@ -923,27 +985,29 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 const double beta2 = wmax(bmax);     // ldl.cl:296-311
                 wave_lds_sync();
                 STAMP(0)
-                // ---- M = A diag(d) A' into registers, t parked in the stage, factor ----
+                // ---- M = A diag(d) A' into registers; factor ----
                 w.gram(Md);
                 STAMP(1)
-                // t, x and (where it fits in front of the tile) z wait in the stage while factor and solve have the registers
+                // cv (in d's place, which is not needed any more: the Newton step forms it again), x and z wait in LDS while
+                // factor and solve have the registers
 #pragma unroll
                 for (int qq = 0; qq < NQ; qq++) {
-                    w.stage_()[lane + 64 * qq] = t[qq];
+                    w.vd_()[lane + 64 * qq] = cv[qq];
                     w.stage_()[64 * NQ + lane + 64 * qq] = x[qq];
                     w.stage_()[128 * NQ + lane + 64 * qq] = z[qq];
                 }
                 const bool viol = w.template factor<false>(beta2, o.pivot_floor STAMP_PASS);
-#pragma unroll
-                for (int qq = 0; qq < NQ; qq++) {
-                    x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
-                    z[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
-                }
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
-                    double dy[MR], wv[NQ], dx[NQ];
+                    double dy[MR], wv[NQ], dx[NQ], e[MR];
                     bool bad;
-                    (void)newton_solve(w, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
+                    (void)newton_solve<true>(w, okc, okr, rho, etol, o.max_refine, mu, dy, dx, wv, e, bad STAMP_PASS);
+#pragma unroll
+                    for (int qq = 0; qq < NQ; qq++) {
+                        cv[qq] = w.vd_()[lane + 64 * qq];
+                        x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                        z[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
+                    }
                     if (bad) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
                     else {
                         // ---- step (primal_normal.cl:158-198) ----
@@ -961,10 +1025,16 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         for (int r2 = 0; r2 < MR; r2++) {
                             const int i = lane + 64 * r2;
                             if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
+                            rho[r2] = fma(-theta, rho[r2] - e[r2], rho[r2]);       // A dx = rho - e
                         }
 #pragma unroll
-                        for (int qq = 0; qq < NQ; qq++) { x[qq] = fma(theta, dx[qq], x[qq]); z[qq] = fma(theta, dz[qq], z[qq]); }
+                        for (int qq = 0; qq < NQ; qq++) {
+                            w.stage_()[64 * NQ + lane + 64 * qq] = fma(theta, dx[qq], x[qq]);
+                            w.stage_()[128 * NQ + lane + 64 * qq] = fma(theta, dz[qq], z[qq]);
+                            w.vd_()[lane + 64 * qq] = okc[qq] ? fma(-theta, wv[qq], cv[qq]) : 0.0;
+                        }
                         normr0 = normr; norms0 = norms;
+                        fresh = false;
                         wave_lds_sync();
                         it++;
                         if (it >= o.max_iter) running = false;   // status stays ITERATION_LIMIT
@@ -978,7 +1048,10 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             if (lane == 0) { const int k = atomicAdd(defer, 1); defer[1 + k] = (int)lp; status[lp] = -1; }
         } else {
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) { const unsigned jo = w.coff(qq); buf_st(rx, jo, x[qq]); buf_st(rz, jo, z[qq]); }     // padded positions and a null z: dropped
+            for (int qq = 0; qq < NQ; qq++) {      // (padded positions and a null z: dropped)
+                const unsigned jo = w.coff(qq);
+                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq]); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq]);
+            }
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
@@ -1376,7 +1449,8 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
         (void)w.template factor<false>(beta2, o.pivot_floor STAMP_PASS);
         double dy[MR], wv[NQ], dx[NQ];
         bool bad;
-        const int nref = newton_solve(w, okc, okr, rho, etol, o.max_refine, dy, dx, wv, bad STAMP_PASS);
+        double ed[MR];
+        const int nref = newton_solve<false>(w, okc, okr, rho, etol, o.max_refine, mu, dy, dx, wv, ed, bad STAMP_PASS);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) if (okr[r2]) dyg[lp * m + lane + 64 * r2] = dy[r2];
         if (nrefg && lane == 0) nrefg[lp] = nref;
