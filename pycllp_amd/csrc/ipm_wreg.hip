@@ -81,6 +81,8 @@ struct WGeo {
     __host__ __device__ static constexpr int bix(int K, int I) { return K * MB - K * (K + 1) / 2 + (I - K - 1); }
     // Gram staging chunks: the off-diagonal blocks in bix order, HB at a time; chunk NCHUNK = the diagonal blocks
     static constexpr int NCHUNK = (NBLK + HB - 1) / HB;
+    // the diagonal blocks' entries ride with the last chunk when its blocks end in front of the W area (where they go)
+    __host__ __device__ static constexpr bool MERGE_DIAG(int NQ) { return NBLK > 0 && (NBLK - HB * (NCHUNK - 1)) * 256 <= stage_d(NQ); }
     static constexpr int WAVE_D(int NQ) { return stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL; }   // per-wave LDS doubles
 };
 
@@ -296,23 +298,37 @@ __device__ __forceinline__ void lds_gather8_pair(const unsigned (&a)[8], double 
                    "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "n"(DELTA) : "memory");
 }
-// gathers: o[k] = *(double*)a[k] resp. o[k] = *(unsigned*)a[k]
-__device__ __forceinline__ void lds_gather4(const unsigned (&a)[4], double (&o)[4]) {
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+// Gram term records: o[k] = *(double*)a[k], c[k] = *(unsigned*)b[k], k < 6 / 4
+__device__ __forceinline__ void lds_gather6_d_u(const unsigned (&a)[6], const unsigned (&b)[6], double (&o)[6], unsigned (&c)[6]) {
+    asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %13\n\tds_read_b64 %2, %14\n\tds_read_b64 %3, %15\n\tds_read_b64 %4, %16\n\tds_read_b64 %5, %17\n\t"
+                 "ds_read_b32 %6, %18\n\tds_read_b32 %7, %19\n\tds_read_b32 %8, %20\n\tds_read_b32 %9, %21\n\tds_read_b32 %10, %22\n\tds_read_b32 %11, %23\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]),
+                   "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]),
+                   "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]) : "memory");
 }
-__device__ __forceinline__ void lds_gather4x2(const unsigned (&a)[4], const unsigned (&b)[4], double (&o)[4], double (&u)[4]) {
-    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
-                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
+__device__ __forceinline__ void lds_gather6(const unsigned (&a)[6], double (&o)[6]) {
+    asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %8\n\tds_read_b64 %3, %9\n\tds_read_b64 %4, %10\n\tds_read_b64 %5, %11\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
 }
-// o[k] = *(double*)a[k], c[k] = *(unsigned*)b[k]
 __device__ __forceinline__ void lds_gather4_d_u(const unsigned (&a)[4], const unsigned (&b)[4], double (&o)[4], unsigned (&c)[4]) {
     asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
                  "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
+}
+__device__ __forceinline__ void lds_gather4(const unsigned (&a)[4], double (&o)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
+// three consecutive term records: w[k] = ((double*)aw)[k], c[k] = ((unsigned*)ac)[k]
+__device__ __forceinline__ void lds_terms3(unsigned aw, unsigned ac, double (&w)[3], unsigned (&c)[3]) {
+    asm volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:16\n\t"
+                 "ds_read_b32 %3, %7\n\tds_read_b32 %4, %7 offset:4\n\tds_read_b32 %5, %7 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]) : "v"(aw), "v"(ac) : "memory");
 }
 
 // ---- the per-wave machinery ------------------------------------------------------------------------------------
@@ -419,38 +435,55 @@ struct WReg {
         }
     }
 
-    // One level of Gram terms, items [i0, i1): dstbuf[t_dst] = (FIRST) or += t_w d[t_col].  FOUR items per lane per trip,
-    // every table read of the trip issued before the first use (one wavefront alone on its SIMD hides no latency by itself)
-    template <bool FIRST>
-    __device__ __forceinline__ void scatter_level(double* dstbuf, int i0, int i1) const {
-        const unsigned wb = lds_addr(t_w), cb = lds_addr(t_cd), db = lds_addr(vd_()), ob = lds_addr(dstbuf);
-        for (int base = i0; base < i1; base += 256) {
-            unsigned aw[4], ac[4], cd[4]; bool on[4]; double wv[4];
+    // First terms of the Gram entries of a group, items [i0, i1): dstbuf[dst] = w d[col].  IPL items per lane per trip, every
+    // table read of the trip in ONE round trip, every d in a second
+    template <int IPL>
+    __device__ __forceinline__ void scatter_first(double* dstbuf, int i0, int i1) const {
+        const unsigned wb = lds_addr(t_w), cb = lds_addr(t_cd), db = lds_addr(vd_());
+        for (int base = i0; base < i1; base += 64 * IPL) {
+            unsigned aw[IPL], ac[IPL], cd[IPL], ad[IPL]; bool on[IPL]; double wv[IPL], dv[IPL];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < IPL; k++) {
                 const int ik = base + lane + 64 * k;
                 on[k] = ik < i1;
                 const int ic = on[k] ? ik : i0;
                 aw[k] = wb + 8 * ic; ac[k] = cb + 4 * ic;
             }
-            lds_gather4_d_u(aw, ac, wv, cd);
-            unsigned ad[4], ao[4]; double dv[4], old[4];
+            if constexpr (IPL == 6) lds_gather6_d_u(aw, ac, wv, cd); else lds_gather4_d_u(aw, ac, wv, cd);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { ad[k] = db + 8 * (cd[k] & 0xffffu); ao[k] = ob + 8 * (cd[k] >> 16); }
-            if (FIRST) lds_gather4(ad, dv); else lds_gather4x2(ad, ao, dv, old);
+            for (int k = 0; k < IPL; k++) ad[k] = db + 8 * (cd[k] & 0xffffu);
+            if constexpr (IPL == 6) lds_gather6(ad, dv); else lds_gather4(ad, dv);
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (on[k]) dstbuf[cd[k] >> 16] = FIRST ? wv[k] * dv[k] : fma(wv[k], dv[k], old[k]);
+            for (int k = 0; k < IPL; k++) if (on[k]) dstbuf[cd[k] >> 16] = wv[k] * dv[k];
         }
     }
-    // all levels of Gram group g into dstbuf (zeroed by the caller: entries the structure does not have stay 0)
+    // Further terms of the entries that have more than one: records in threes (the 2nd..4th term of an entry, then its
+    // 5th..7th in the next round, ...; short triples padded with weight 0), one entry per lane, added to the entry in term order
+    __device__ __forceinline__ void scatter_more(double* dstbuf, int i0, int i1) const {
+        const unsigned wb = lds_addr(t_w), cb = lds_addr(t_cd), db = lds_addr(vd_()), ob = lds_addr(dstbuf);
+        for (int base = i0; base < i1; base += 192) {
+            const int ik = base + 3 * lane;
+            const bool on = ik < i1;
+            const int ic = on ? ik : i0;
+            double wv[3], dv[4]; unsigned cd[3], ad[4];
+            lds_terms3(wb + 8 * ic, cb + 4 * ic, wv, cd);
+#pragma unroll
+            for (int k = 0; k < 3; k++) ad[k] = db + 8 * (cd[k] & 0xffffu);
+            ad[3] = ob + 8 * (cd[0] >> 16);
+            lds_gather4(ad, dv);
+            const double acc = fma(wv[2], dv[2], fma(wv[1], dv[1], fma(wv[0], dv[0], dv[3])));
+            if (on) dstbuf[cd[0] >> 16] = acc;
+        }
+    }
+    // all terms of Gram group g into dstbuf (zeroed by the caller: entries the structure does not have stay 0)
     __device__ __forceinline__ void scatter_group(double* dstbuf, int g) const {
         const int l0 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g]), l1 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g + 1]);
         if (l0 < l1) {
             int i0 = __builtin_amdgcn_readfirstlane(lev[l0]), i1 = __builtin_amdgcn_readfirstlane(lev[l0 + 1]);
-            scatter_level<true>(dstbuf, i0, i1);
+            if (i1 - i0 > 256) scatter_first<6>(dstbuf, i0, i1); else scatter_first<4>(dstbuf, i0, i1);
             for (int l = l0 + 1; l < l1; l++) {
                 i0 = i1; i1 = __builtin_amdgcn_readfirstlane(lev[l + 1]);
-                scatter_level<false>(dstbuf, i0, i1);
+                scatter_more(dstbuf, i0, i1);
             }
         }
     }
@@ -460,16 +493,33 @@ struct WReg {
     // slots of the W area, where factor() picks block K up when its turn comes and then overwrites it with W_K.
     __device__ __forceinline__ void gram(const double (&Md)[MR]) {
         static_assert(HB * 256 <= STAGE_D + MB * WL, "staging area too small");
+        static_assert((MB * WL) % 128 == 0, "diagonal-block slots are zeroed in whole b128 wavefront stores");
+        const double2_t zero = {0.0, 0.0};
+        // zero the diagonal-block slots, scatter group g's diagonal-block entries (dsts relative to `base`), set the diagonal
+        // from Md (row 16K + i lives in lane (16K + i) % 64 of register (16K + i) / 64)
+        auto zero_slots = [&]() {
+#pragma unroll
+            for (int w = 0; w < (MB * WL) / 128; w++) ((double2_t*)wl_())[w * 64 + lane] = zero;
+        };
+        auto set_diag = [&]() {
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const int row = lane + 64 * r2, il = row & 15;
+                if (row < MP) wl_()[(row >> 4) * WL + il * (il + 1) / 2 + il] = Md[r2];
+            }
+        };
         static_for<0, G::NCHUNK>([&](auto cc) {
             constexpr int ci = decltype(cc)::value;
             constexpr int b0 = HB * ci;
             constexpr int nb = (G::NBLK - b0 < HB) ? G::NBLK - b0 : HB;
-            const double2_t zero = {0.0, 0.0};
+            constexpr bool with_diag = G::MERGE_DIAG(NQ) && ci == G::NCHUNK - 1;     // the last chunk leaves the W area alone
             pin();
 #pragma unroll
             for (int w = 0; w < 2 * nb; w++) ((double2_t*)stage_())[w * 64 + lane] = zero;
+            if constexpr (with_diag) zero_slots();
             wave_lds_sync();
             scatter_group(stage_(), ci);
+            if constexpr (with_diag) set_diag();
             wave_lds_sync();
             static_assert(nb % 4 == 0, "block loads go four blocks (16 registers) at a time");
 #pragma unroll
@@ -484,21 +534,14 @@ struct WReg {
             }
             wave_lds_sync();
         });
-        // diagonal blocks: strict lower triangle from the entry tables, the diagonal from Md (row 16K + i lives in lane
-        // (16K + i) % 64 of register (16K + i) / 64)
-        const double2_t zero = {0.0, 0.0};
-        pin();
-        static_assert((MB * WL) % 128 == 0, "diagonal-block slots are zeroed in whole b128 wavefront stores");
-#pragma unroll
-        for (int w = 0; w < (MB * WL) / 128; w++) ((double2_t*)wl_())[w * 64 + lane] = zero;
-        wave_lds_sync();
-        scatter_group(wl_(), G::NCHUNK);
-#pragma unroll
-        for (int r2 = 0; r2 < MR; r2++) {
-            const int row = lane + 64 * r2, il = row & 15;
-            if (row < MP) wl_()[(row >> 4) * WL + il * (il + 1) / 2 + il] = Md[r2];
+        if constexpr (!G::MERGE_DIAG(NQ)) {       // diagonal blocks as a group of their own (dsts relative to the stage as well)
+            pin();
+            zero_slots();
+            wave_lds_sync();
+            scatter_group(stage_(), G::NCHUNK);
+            set_diag();
+            wave_lds_sync();
         }
-        wave_lds_sync();
     }
 
     // W_K element [row 4s + q][column c16] -- the TRANSPOSED operand layout -- from the packed copy in LDS
@@ -896,7 +939,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         // taken again on the exact ones (as the dense group kernel does for rho), and the iteration goes on if it fails.
         // x, z and cv cross the loop's back edge IN LDS (the slots where they wait during factor and solve anyway), not in
         // registers: 36 loop-carried registers through this loop's control flow end up in scratch
-        double rho[MR];
+        // (rho lives in the floor vector's place, which this kernel does not use)
         bool refresh = true, fresh = false;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
@@ -906,7 +949,9 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         wave_lds_sync();
 
         while (running) {
-            double x[NQ], z[NQ], cv[NQ];
+            double x[NQ], z[NQ], cv[NQ], rho[MR];
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) rho[r2] = w.flr_()[lane + 64 * r2];
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
                 x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
@@ -927,7 +972,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 wave_lds_sync();
                 w.template Arow<false>(vx, Ax, dm);
 #pragma unroll
-                for (int r2 = 0; r2 < MR; r2++) rho[r2] = okr[r2] ? w.bs_()[lane + 64 * r2] - Ax[r2] : 0.0;
+                for (int r2 = 0; r2 < MR; r2++) { rho[r2] = okr[r2] ? w.bs_()[lane + 64 * r2] - Ax[r2] : 0.0; w.flr_()[lane + 64 * r2] = rho[r2]; }
                 wave_lds_sync();
                 refresh = false; fresh = true;
             }
@@ -999,9 +1044,11 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 const bool viol = w.template factor<false>(beta2, o.pivot_floor STAMP_PASS);
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
-                    double dy[MR], wv[NQ], dx[NQ], e[MR];
+                    double dy[MR], wv[NQ], dx[NQ], e[MR], rhn[MR];
                     bool bad;
-                    (void)newton_solve<true>(w, okc, okr, rho, etol, o.max_refine, mu, dy, dx, wv, e, bad STAMP_PASS);
+#pragma unroll
+                    for (int r2 = 0; r2 < MR; r2++) rhn[r2] = w.flr_()[lane + 64 * r2];
+                    (void)newton_solve<true>(w, okc, okr, rhn, etol, o.max_refine, mu, dy, dx, wv, e, bad STAMP_PASS);
 #pragma unroll
                     for (int qq = 0; qq < NQ; qq++) {
                         cv[qq] = w.vd_()[lane + 64 * qq];
@@ -1025,7 +1072,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         for (int r2 = 0; r2 < MR; r2++) {
                             const int i = lane + 64 * r2;
                             if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
-                            rho[r2] = fma(-theta, rho[r2] - e[r2], rho[r2]);       // A dx = rho - e
+                            w.flr_()[i] = fma(-theta, rhn[r2] - e[r2], rhn[r2]);       // A dx = rho - e
                         }
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) {
@@ -1660,47 +1707,74 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
         }
     }
     // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk (HB blocks of the
-    //      linear block order each), then the entries inside the diagonal blocks, addressed relative to the W area ----
+    //      linear block order each); the entries inside the diagonal blocks go to their slots in the W area, as part of
+    //      the last chunk's group when that chunk ends in front of the W area, else as a group of their own.  All
+    //      destinations are offsets from the start of the stage. ----
     struct Term { int group, dst, colj; double w; };
     std::vector<Term> terms;
     const int nblk = MB * (MB - 1) / 2, nchunk = (nblk + HB - 1) / HB;
-    if (nchunk + 2 > META_N - META_SEG) { delete P; return 1; }
+    const bool merge_diag = nblk > 0 && (nblk - HB * (nchunk - 1)) * 256 <= stage_d(NQ);      // = WGeo<MB>::MERGE_DIAG(NQ)
+    const int diag_group = merge_diag ? nchunk - 1 : nchunk, ngroup = merge_diag ? nchunk : nchunk + 1;
+    if (ngroup + 1 > META_N - META_SEG || stage_d(NQ) + MB * WL > 65535) { delete P; return 1; }
     for (int j = 0; j < n; j++)
         for (int a = cptr[j]; a < cptr[j + 1]; a++)
             for (int b2 = cptr[j]; b2 < a; b2++) {
                 const int i = crow[a], k = crow[b2];   // rows ascend inside a column: i > k
                 const int K = k / 16, I = i / 16, il = i % 16, kl = k % 16;
                 if (I == K) {          // diagonal block K: element [il][kl] of the packed lower triangle in slot K
-                    terms.push_back({nchunk, K * WL + il * (il + 1) / 2 + kl, posof[j], csc_val[a] * csc_val[b2]});
+                    terms.push_back({diag_group, stage_d(NQ) + K * WL + il * (il + 1) / 2 + kl, posof[j], csc_val[a] * csc_val[b2]});
                 } else {               // block (K, I) of U: element [kl][il] of block bix % HB of chunk bix / HB
                     const int bx = K * MB - K * (K + 1) / 2 + (I - K - 1);
                     terms.push_back({bx / HB, (bx % HB) * 256 + kl * 16 + il, posof[j], csc_val[a] * csc_val[b2]});
                 }
                 if (terms.size() > ((size_t)1 << 22)) { delete P; return 1; }
             }
-    // level of a term = its rank inside its entry, in column order (the order a per-entry loop would add them in)
+    // Records of a group: first the FIRST term of every entry (one flat pass), then rounds of triples -- terms 2..4 of the
+    // entries that have them, then terms 5..7, ... -- in column order (the order a per-entry loop would add them in), short
+    // triples padded with weight 0.  lev[] holds the record boundaries, meta[META_SEG + g] the first boundary of group g.
     std::stable_sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) {
         return a.group != b.group ? a.group < b.group : a.dst < b.dst; });
-    std::vector<int> level(terms.size(), 0);
-    for (size_t t = 1; t < terms.size(); t++)
-        if (terms[t].group == terms[t - 1].group && terms[t].dst == terms[t - 1].dst) level[t] = level[t - 1] + 1;
-    std::vector<size_t> ord(terms.size());
-    for (size_t t = 0; t < ord.size(); t++) ord[t] = t;
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
-        return terms[a].group != terms[b].group ? terms[a].group < terms[b].group : level[a] < level[b]; });
-    const int ngroup = nchunk + 1;
-    std::vector<double> t_w(terms.size());
-    std::vector<unsigned> t_cd(terms.size());
+    std::vector<double> t_w;
+    std::vector<unsigned> t_cd;
     std::vector<int> lev(1, 0), gl(ngroup + 1, 0);
-    for (size_t u = 0; u < ord.size(); u++) {
-        const Term& tm = terms[ord[u]];
-        t_w[u] = tm.w; t_cd[u] = (unsigned)tm.colj | ((unsigned)tm.dst << 16);
-        const bool last = u + 1 == ord.size() || terms[ord[u + 1]].group != tm.group || level[ord[u + 1]] != level[ord[u]];
-        if (last) { lev.push_back((int)u + 1); gl[tm.group + 1] = (int)lev.size() - 1; }
+    {
+        size_t t0 = 0;
+        for (int g = 0; g < ngroup; g++) {
+            size_t t1 = t0;
+            while (t1 < terms.size() && terms[t1].group == g) t1++;
+            gl[g] = (int)lev.size() - 1;
+            // entries of the group: [e0, e1) term ranges
+            std::vector<std::pair<size_t, size_t>> ent;
+            for (size_t t = t0; t < t1;) {
+                size_t u = t + 1;
+                while (u < t1 && terms[u].dst == terms[t].dst) u++;
+                ent.push_back({t, u}); t = u;
+            }
+            if (!ent.empty()) {
+                for (auto& e : ent) { t_w.push_back(terms[e.first].w); t_cd.push_back((unsigned)terms[e.first].colj | ((unsigned)terms[e.first].dst << 16)); }
+                lev.push_back((int)t_w.size());
+                for (size_t r = 0;; r++) {
+                    bool any = false;
+                    for (auto& e : ent) {
+                        const size_t f = e.first + 1 + 3 * r;
+                        if (f >= e.second) continue;
+                        any = true;
+                        for (size_t k = 0; k < 3; k++) {
+                            const bool have = f + k < e.second;
+                            t_w.push_back(have ? terms[f + k].w : 0.0);
+                            t_cd.push_back((have ? (unsigned)terms[f + k].colj : 0u) | ((unsigned)terms[e.first].dst << 16));
+                        }
+                    }
+                    if (!any) break;
+                    lev.push_back((int)t_w.size());
+                }
+            }
+            t0 = t1;
+        }
+        gl[ngroup] = (int)lev.size() - 1;
     }
-    for (int g = 1; g <= ngroup; g++) gl[g] = std::max(gl[g], gl[g - 1]);
     for (int g = 0; g <= ngroup; g++) T.meta[META_SEG + g] = gl[g];
-    T.n_lev = (int)lev.size() - 1; T.n_term = (int)terms.size();
+    T.n_lev = (int)lev.size() - 1; T.n_term = (int)t_w.size();
     if (t_w.empty()) { t_w.push_back(0.0); t_cd.push_back(0); }
     // ---- LDS plan ----
     size_t off = 0;
