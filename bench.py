@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hsd", action="store_true", help="sparse5 only: time the homogeneous self-dual variant (PYCLLP_FLAG_HSD)")
     ap.add_argument("--workload", choices=("dense3", "sparse5"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
@@ -177,8 +178,9 @@ def main():
         Nn = n_ + m_
         from pycllp_amd.lp import StandardLP
         lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
-        # hsd=True: the homogeneous self-dual variant needs 41 instead of 52 iterations on this workload
-        solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=True, reserve_cus=reserve)
+        # the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto' runs first;
+        # --hsd: the homogeneous self-dual variant (41 instead of 52 iterations on this workload, two solves per iteration)
+        solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=bool(args.hsd), reserve_cus=reserve)
         cpu = None
     else:
         m_, n_ = M, N_STD
@@ -242,6 +244,7 @@ def main():
     gathered = pg.results(args.steps - 1, names=fields) if multi else None
 
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+    info = solver.launch_info()      # of the timed launches (the parity solve below launches again, with another batch)
     status = buf["status"].cpu().numpy()
     iters = buf["iters"].cpu().numpy()
     pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
@@ -310,7 +313,6 @@ def main():
             ent = tj.get("sparse5" if sparse else "dense3")
             if ent and ent.get("lps_per_launch") == B and world == 1:
                 traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
-        info = solver.launch_info()
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -324,9 +326,10 @@ def main():
                                     % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
                        "lps_per_gpu": B, "lps_total": B * world, "m": m_, "n": n_, "N_equality": Nn,
                        "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world, "reserve_cus": reserve,
-                       "kernel": ("%s, PYCLLP_FLAG_HSD, grid %d x block %d, %d B LDS"
-                                  % ("hsd_wreg_kernel (one LP per wavefront, factor in registers)" if info["kernel"] == "wave" else
-                                     "ipm_block_kernel (one LP per 256-thread workgroup)", info["grid"], info["block"], info["lds_bytes"]))
+                       "kernel": ("%s%s, grid %d x block %d, %d B LDS"
+                                  % (("hsd_wreg_kernel" if args.hsd else "ipm_wreg_kernel") + " (one LP per wavefront, factor in registers)"
+                                     if info["kernel"] == "wave" else "ipm_block_kernel (one LP per 256-thread workgroup)",
+                                     ", PYCLLP_FLAG_HSD" if args.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
                                  if sparse else
                                  "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
                                  % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},

@@ -85,7 +85,7 @@ typedef struct pycllp_hip_opts {
     double refine_tol;  /* refinement tolerance on max|b-Ax-A dx|, relative to 1+|b|, default
                            1e-11 (reference: 1e-8 absolute on rhs-M dy, ldl.cl:645)          */
     int max_iter;       /* default 200 (primal_normal.cl:9)                                  */
-    int max_refine;     /* default 5 (ldl.cl:645)                                            */
+    int max_refine;     /* default 5 (ldl.cl:645); with PYCLLP_FLAG_HSD use 20   */
     int flags;          /* PYCLLP_FLAG_*                                                     */
     int reserve_cus;    /* compute units the solve leaves idle (default 0).  The solve kernels are persistent and fill every CU
                            completely (LDS and registers), so a kernel on another stream -- e.g. the RCCL copy kernels of the

@@ -44,6 +44,8 @@ def default_opts(**kw):
         if not hasattr(o, k):
             raise TypeError("unknown option %r" % k)
         setattr(o, k, v)
+    if "max_refine" not in kw and (o.flags & 32):     # PYCLLP_FLAG_HSD: the product's default for that variant
+        o.max_refine = 20                             # (pycllp_amd/_native.py HSD_MAX_REFINE, reasons there)
     return o
 
 

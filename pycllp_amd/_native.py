@@ -93,6 +93,14 @@ def lib():
     return L
 
 
+# The reference caps the refinement of its Newton systems at 5 passes (pycllp/cl/ldl.cl:645), which the plain path keeps.
+# The homogeneous self-dual variant is this package's addition and its systems are harder near the end: with a cap of 5
+# the degenerate LP 7557 of config 5's share sits at a 1.6e-10 relative gap for 70-150 iterations (oracle: 118 in all,
+# the kernels 58-200 depending on rounding), with 10 passes it needs 48 iterations, with 20 passes 39.  No other LP of
+# the test workloads uses more than 5.
+HSD_MAX_REFINE = 20
+
+
 def default_opts(**kw):
     o = Opts()
     lib().pycllp_hip_default_opts(ctypes.byref(o))
@@ -100,6 +108,8 @@ def default_opts(**kw):
         if k not in dict(Opts._fields_):
             raise TypeError("unknown solver option %r" % k)
         setattr(o, k, v)
+    if "max_refine" not in kw and (o.flags & FLAG_HSD):
+        o.max_refine = HSD_MAX_REFINE
     return o
 
 
