@@ -121,4 +121,67 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int K>
 __device__ __forceinline__ double row_bcast(double v) { return dpp_d<0x150 + K>(v); }
 
+// ---- 64-bit DPP (gfx90a+: the DP ALU takes row_newbcast) ---------------------------------------------------------
+// The compiler builds a row broadcast of a double from two v_mov_b32_dpp and feeds the copy to the FMA; the hardware can
+// broadcast inside the 64-bit instruction itself.  The s_nop covers the VALU-write -> DPP-read hazard (2 wait states),
+// which the hazard recogniser does not see through inline asm.
+#define DPP_STR_(x) #x
+#define DPP_STR(x) DPP_STR_(x)
+// v of lane K of each 16-lane row
+template <int K>
+__device__ __forceinline__ double bcast64(double v) {
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" DPP_STR(%2) " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+// Pivot step J of the 16-step chain: Wd[k] += (u of lane k of the row) * nli for k = J+1 .. 15, one fused 64-bit DPP FMA
+// each (J = -1: all sixteen, k = 0 .. 15).  ONE asm statement per step, with a leading s_nop: the compiler may have produced u (or moved it between register
+// files) in the instruction just before, and the hazard recogniser does not look inside inline asm.
+template <int J>
+__device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nli) {
+    asm volatile("s_nop 1\n\t"
+                 ".if 0 > %18\n\tv_fmac_f64_dpp %0, %16, %17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 1 > %18\n\tv_fmac_f64_dpp %1, %16, %17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 2 > %18\n\tv_fmac_f64_dpp %2, %16, %17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 3 > %18\n\tv_fmac_f64_dpp %3, %16, %17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 4 > %18\n\tv_fmac_f64_dpp %4, %16, %17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 5 > %18\n\tv_fmac_f64_dpp %5, %16, %17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 6 > %18\n\tv_fmac_f64_dpp %6, %16, %17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 7 > %18\n\tv_fmac_f64_dpp %7, %16, %17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 8 > %18\n\tv_fmac_f64_dpp %8, %16, %17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 9 > %18\n\tv_fmac_f64_dpp %9, %16, %17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 10 > %18\n\tv_fmac_f64_dpp %10, %16, %17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 11 > %18\n\tv_fmac_f64_dpp %11, %16, %17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 12 > %18\n\tv_fmac_f64_dpp %12, %16, %17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 13 > %18\n\tv_fmac_f64_dpp %13, %16, %17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 14 > %18\n\tv_fmac_f64_dpp %14, %16, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 15 > %18\n\tv_fmac_f64_dpp %15, %16, %17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15])
+                 : "v"(u), "v"(nli), "n"(J));
+}
+
+// ---- batched LDS reads (see ipm_wreg.hip for the rest of the family) -------------------------------------------
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+#define LDS_RD_(i) "ds_read_b64 %" #i ", %16 offset:%17+%18*" #i "\n\t"
+// o[i] = *(double*)(a + OFF0 + STRIDE i), i < 16 (byte address / offsets)
+template <int OFF0, int STRIDE>
+__device__ __forceinline__ void lds_run16(unsigned a, double* o) {
+    asm volatile(LDS_RD_(0) LDS_RD_(1) LDS_RD_(2) LDS_RD_(3) LDS_RD_(4) LDS_RD_(5) LDS_RD_(6) LDS_RD_(7) LDS_RD_(8) LDS_RD_(9)
+                 LDS_RD_(10) LDS_RD_(11) LDS_RD_(12) LDS_RD_(13) LDS_RD_(14) LDS_RD_(15) "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                 : "v"(a), "n"(OFF0), "n"(STRIDE) : "memory");
+}
+template <int OFF0, int STRIDE>
+__device__ __forceinline__ void lds_run8(unsigned a, double* o) {
+    asm volatile("ds_read_b64 %0, %8 offset:%9+%10*0\n\tds_read_b64 %1, %8 offset:%9+%10*1\n\tds_read_b64 %2, %8 offset:%9+%10*2\n\t"
+                 "ds_read_b64 %3, %8 offset:%9+%10*3\n\tds_read_b64 %4, %8 offset:%9+%10*4\n\tds_read_b64 %5, %8 offset:%9+%10*5\n\t"
+                 "ds_read_b64 %6, %8 offset:%9+%10*6\n\tds_read_b64 %7, %8 offset:%9+%10*7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                 : "v"(a), "n"(OFF0), "n"(STRIDE) : "memory");
+}
+#undef LDS_RD_
+
 #endif  // PYCLLP_WAVE_COMMON_H
