@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hsd", action="store_true", help="sparse5 only: time the homogeneous self-dual variant (PYCLLP_FLAG_HSD)")
-    ap.add_argument("--workload", choices=("dense3", "sparse5"), default="dense3",
+    ap.add_argument("--workload", choices=("dense3", "sparse5", "perA"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
     ap.add_argument("--sync-gather", action="store_true", help="block on the result gather after every solve (no overlap)")
@@ -165,7 +165,8 @@ def main():
         cpu_all = cpu_port(cpu["value"] if cpu["kind"] == "reference" else None)
 
     B = args.batch
-    sparse = args.workload == "sparse5"
+    per_a = args.workload == "perA"       # one structure, every LP its own values of A (read from HBM per LP)
+    sparse = args.workload == "sparse5" or per_a
     if sparse:
         if args.batch == B_PER_GPU:
             B = 16384
@@ -177,7 +178,13 @@ def main():
         be, ce = b, np.hstack([c, np.zeros((B, m_))])
         Nn = n_ + m_
         from pycllp_amd.lp import StandardLP
-        lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
+        if per_a:
+            # the structure of configs[4]'s A, values of LP k = the shared ones x U[0.75, 1.25) per entry (seed 7 + rank)
+            Ac = A.tocoo()
+            data = Ac.data[None, :] * (0.75 + 0.5 * np.random.RandomState(7 + rank).rand(B, Ac.nnz))
+            lp = StandardLP(SparseMatrix(Ac.row, Ac.col, data), b, c, 0.0).to_equality_form()
+        else:
+            lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
         # the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto' runs first;
         # --hsd: the homogeneous self-dual variant (41 instead of 52 iterations on this workload, two solves per iteration)
         solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=bool(args.hsd), reserve_cus=reserve)
@@ -190,6 +197,8 @@ def main():
         lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
         solver = solver_registry["hip_dense_primal_normal"](device=dev, reserve_cus=reserve)
     lp.init(solver)
+    if per_a:      # the values travel once, like b and c: resident in HBM when the timed region starts
+        solver._a_values = torch.as_tensor(np.ascontiguousarray(np.asarray(lp.A.data, dtype=np.float64)[:, solver._a_perm]), device=dev)
     bd = torch.as_tensor(be, device=dev)
     cd = torch.as_tensor(ce, device=dev)
     sizes = [B] * world
@@ -268,6 +277,21 @@ def main():
         gpath = os.path.join(ROOT, "tests", "golden", "config_32x64.npz")
         if sparse:
             import scipy.sparse as sp
+        if per_a:
+            # no reference fixture exists for this extension (the reference's LP classes refuse per-problem A, lp.py:335-336):
+            # the first LPs are checked against the oracle run with THEIR OWN matrices
+            from oracle import port
+            kk = 8
+            pv = buf["pobj"].cpu().numpy(); dv = buf["dobj"].cpu().numpy()
+            ep = ed = 0.0
+            for k in range(kk):
+                r = port.dense_solve(lp.A.todense(k), be[k:k + 1], ce[k:k + 1])
+                ep = max(ep, abs(pv[k] - r["pobj"][0]) / max(1.0, abs(r["pobj"][0])))
+                ed = max(ed, abs(dv[k] - r["dobj"][0]) / max(1.0, abs(r["dobj"][0])))
+            parity = {"oracle_lps": kk, "max_rel_err_primal_obj": float(ep), "max_rel_err_dual_obj": float(ed), "tolerance": 1e-8,
+                      "source": "oracle/ipm_dense_ref.c on the first LPs with their own matrices (parity unpinned by the "
+                                "reference: it has no per-problem-A path)"}
+        elif sparse:
             g = np.load(os.path.join(ROOT, "tests", "golden", "config_sparse_128x256.npz"))
             r = solver.solve_device(g["b"], np.hstack([g["c"], np.zeros((g["c"].shape[0], m_))]))
             torch.cuda.synchronize(dev)
@@ -301,8 +325,9 @@ def main():
         # columns only (the identity columns of [A | I] bypass them); the sparse formula above already counts executed work
         f_exec = f_lp if sparse else iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
         tflops_exec = f_exec * B / (kern_ms * 1e-3) / 1e12
-        b_survey = 16 * (m_ + Nn) + 24                       # b, c in; x, y out; objectives; status, iters
-        b_with_z = bytes_per_lp(m_, Nn)                      # + the dual slacks z this library also returns
+        a_bytes = 8 * (int(A.nnz) + m_) if per_a else 0      # per-problem A: every LP reads its own values (equality form)
+        b_survey = 16 * (m_ + Nn) + 24 + a_bytes             # b, c in; x, y out; objectives; status, iters
+        b_with_z = bytes_per_lp(m_, Nn) + a_bytes            # + the dual slacks z this library also returns
         gbs = b_survey * B / (kern_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
         # passes): a profile-sourced figure, attached only when this run is the profiled configuration
@@ -310,7 +335,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            ent = tj.get("sparse5" if sparse else "dense3")
+            ent = tj.get(args.workload)
             if ent and ent.get("lps_per_launch") == B and world == 1:
                 traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
         out = {
@@ -319,8 +344,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL on one shared GPU: not a result)",
             "config": {"workload": ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 "
-                                    "non-zeros) -> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)"
-                                    % (B, m_, n_, Nn)) if sparse else
+                                    "non-zeros) -> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)%s"
+                                    % (B, m_, n_, Nn, "; PER-PROBLEM VALUES of A on that structure (SURVEY 8f-4; shared x U[0.75,1.25))"
+                                       if per_a else "")) if sparse else
                                    ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
                                     "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
                                     % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
