@@ -336,7 +336,7 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             ent = tj.get(args.workload)
-            if ent and ent.get("lps_per_launch") == B and world == 1:
+            if ent and ent.get("lps_per_launch") == B and world == 1 and not args.hsd:
                 traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
