@@ -1136,8 +1136,22 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         double po = 0.0, du = 0.0;
         int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
         bool running = true;
+        // x and z cross the loop's back edge in LDS (the slots where they wait during factor and solves), as in ipm_wreg_kernel
+#pragma unroll
+        for (int qq = 0; qq < NQ; qq++) {
+            w.stage_()[64 * NQ + lane + 64 * qq] = x[qq];
+            w.stage_()[128 * NQ + lane + 64 * qq] = z[qq];
+        }
+        wave_lds_sync();
 
         while (running) {
+            double x[NQ], z[NQ];
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                z[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
+            }
+            wave_lds_sync();
             // ---- sigma = c tau - A'y + z, gamma, objectives ----
             double v[NQ], cq[NQ], sg[NQ];
 #pragma unroll
@@ -1221,29 +1235,42 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 STAMP(0)
                 w.gram(Md);
                 STAMP(1)
+                // t = r1, x and z wait in the stage while factor and the solves have the registers
 #pragma unroll
-                for (int qq = 0; qq < NQ; qq++) w.stage_()[lane + 64 * qq] = t[qq];
+                for (int qq = 0; qq < NQ; qq++) {
+                    w.stage_()[lane + 64 * qq] = t[qq];
+                    w.stage_()[64 * NQ + lane + 64 * qq] = x[qq];
+                    w.stage_()[128 * NQ + lane + 64 * qq] = z[qq];
+                }
                 const bool viol = w.template factor<true>(beta2, 0.0 STAMP_PASS);
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
                     // ---- one loop around the ONE copy of the block substitution: pass 0 solves for p, pass 1 for q and
                     //      combines them through dtau, the following passes are the x-space refinement ----
-                    double d[NQ], dx[NQ], u[NQ] /* c - A'p */, dy[MR], rhot[MR];
-#pragma unroll
-                    for (int qq = 0; qq < NQ; qq++) d[qq] = okc[qq] ? x[qq] * fast_rcp(z[qq]) : 0.0;
+                    // (u = c - A'p waits in d's place between the two solves: d = x / z is formed again from the parked x, z
+                    // where a pass needs it; c comes back from memory, in flight while the substitution runs)
+                    double dx[NQ], dy[MR], rhot[MR];
                     double dtau = 0.0, etol_it = 0.0;
                     bool bad = false;
                     int pass = 0;
                     for (;;) {
+                        double c2q[NQ];
+                        if (pass < 2) {
+#pragma unroll
+                            for (int qq = 0; qq < NQ; qq++) c2q[qq] = buf_ld(rc, w.coff(qq));
+                        }
                         w.solve();
                         STAMP(7)
-                        double w2[NQ];
+                        double w2[NQ], d[NQ];
                         w.At(w.um_(), w2);
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++)
+                            d[qq] = okc[qq] ? w.stage_()[64 * NQ + lane + 64 * qq] * fast_rcp(w.stage_()[128 * NQ + lane + 64 * qq]) : 0.0;
                         bool more = true;
                         if (pass == 0) {
-                            // c - A'p is kept; p moves to pv, q's right-hand side into um
+                            // c - A'p is kept (in d's place); p moves to pv, q's right-hand side into um
 #pragma unroll
-                            for (int qq = 0; qq < NQ; qq++) u[qq] = cq[qq] - w2[qq];
+                            for (int qq = 0; qq < NQ; qq++) w.vd_()[lane + 64 * qq] = c2q[qq] - w2[qq];
                             wave_lds_sync();
 #pragma unroll
                             for (int r2 = 0; r2 < MR; r2++) {
@@ -1254,12 +1281,14 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         } else {
                             if (pass == 1) {
                                 double dsum = 0.0, nsum = 0.0, bq = 0.0;
+                                double u[NQ];
 #pragma unroll
                                 for (int qq = 0; qq < NQ; qq++) {
                                     const double tq = w.stage_()[lane + 64 * qq];
+                                    u[qq] = w.vd_()[lane + 64 * qq];
                                     dx[qq] = d[qq] * (tq - w2[qq]);                       // v = d (r1 - A'q)
                                     dsum = fma(d[qq] * u[qq], u[qq], dsum);               // |sqrt(d)(c - A'p)|^2
-                                    nsum = fma(cq[qq], dx[qq], nsum);                     // c'v
+                                    nsum = fma(c2q[qq], dx[qq], nsum);                    // c'v
                                 }
 #pragma unroll
                                 for (int r2 = 0; r2 < MR; r2++) {
@@ -1312,11 +1341,16 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                     else {
                         // ---- step: ratio test over x, z, tau, kappa ----
                         const double dkap = mu / tau - kap - kap / tau * dtau;
-                        double dz[NQ], th = fmax(fmax(-dtau / tau, -dkap / kap), 0.0);
+                        double dz[NQ], xs[NQ], zs[NQ], th = fmax(fmax(-dtau / tau, -dkap / kap), 0.0);
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) {
-                            const double rx = fast_rcp(x[qq]), rz = fast_rcp(z[qq]);
-                            dz[qq] = okc[qq] ? (mu - z[qq] * dx[qq]) * rx - z[qq] : 0.0;
+                            xs[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
+                            zs[qq] = w.stage_()[128 * NQ + lane + 64 * qq];
+                        }
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) {
+                            const double rx = fast_rcp(xs[qq]), rz = fast_rcp(zs[qq]);
+                            dz[qq] = okc[qq] ? (mu - zs[qq] * dx[qq]) * rx - zs[qq] : 0.0;
                             if (okc[qq]) th = fmax(th, fmax(-dz[qq] * rz, -dx[qq] * rx));
                         }
                         th = wmax(th);
@@ -1328,7 +1362,10 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                             if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
                         }
 #pragma unroll
-                        for (int qq = 0; qq < NQ; qq++) { x[qq] = fma(theta, dx[qq], x[qq]); z[qq] = fma(theta, dz[qq], z[qq]); }
+                        for (int qq = 0; qq < NQ; qq++) {
+                            w.stage_()[64 * NQ + lane + 64 * qq] = fma(theta, dx[qq], xs[qq]);
+                            w.stage_()[128 * NQ + lane + 64 * qq] = fma(theta, dz[qq], zs[qq]);
+                        }
                         tau = uni(fma(theta, dtau, tau)); kap = uni(fma(theta, dkap, kap));
                         wave_lds_sync();
                         it++;
@@ -1345,7 +1382,10 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
             // optimal (and iteration-limit) points leave the homogeneous scaling (hsd.c:266-273); certificates stay
             const double rt = (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT) ? 1.0 / tau : 1.0;
 #pragma unroll
-            for (int qq = 0; qq < NQ; qq++) { const unsigned jo = w.coff(qq); buf_st(rx, jo, x[qq] * rt); buf_st(rz, jo, z[qq] * rt); }   // padded positions, null z: dropped
+            for (int qq = 0; qq < NQ; qq++) {      // (padded positions, null z: dropped)
+                const unsigned jo = w.coff(qq);
+                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq] * rt); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq] * rt);
+            }
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
