@@ -561,22 +561,29 @@ struct WReg {
             STAMP(3)
             const double myf = RELF ? flr_()[16 * K + c16] : floor_;
             wave_lds_sync();
-            double rdiag = 1.0;
+            double rdiag = 1.0, aD, rD;
+            {
+                const double piv = bcast64<0>(Wd[0]);
+                aD = fmax(fabs(piv), RELF ? row_bcast<0>(myf) : floor_);
+                rD = fast_rcp(aD);
+            }
             static_for<0, 16>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const double u = Wd[j];
-                const double piv = bcast64<j>(u);
-                const double aD = fmax(fabs(piv), RELF ? row_bcast<j>(myf) : floor_);
-                const double rD = fast_rcp(aD);
                 const bool below = c16 > j;
                 viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
                 const double nli = below ? -(u * rD) : 0.0;
-                if constexpr (j < 15) chain_step<j>(Wd, u, nli);      // Wd[k] -= l_i u_k, k > j
                 Ld[j] = nli;
                 rdiag = (c16 == j) ? rD : rdiag;
                 // select NOW: deferred to the end of the chain (where the scheduler sinks them) the selects keep all
                 // 16 reciprocals alive and the chain spills
                 asm volatile("" : "+v"(rdiag), "+v"(viol));
+                if constexpr (j < 15) {      // Wd[k] -= l_i u_k, k > j, with the next pivot's reciprocal chain in between (chain_asm.inc)
+                    double aDn, rDn;
+                    if constexpr (RELF) chain_step_pipe_relf<j>(Wd, u, nli, floor_, myf, aDn, rDn);
+                    else chain_step_pipe<j>(Wd, u, nli, floor_, aDn, rDn);
+                    aD = aDn; rD = rDn;
+                }
             });
             if (q == 0) rdv_()[16 * K + c16] = rdiag;
             STAMP(4)

@@ -160,6 +160,8 @@ __device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nl
                  : "v"(u), "v"(nli), "n"(J));
 }
 
+#include "chain_asm.inc"
+
 // ---- batched LDS reads (see ipm_wreg.hip for the rest of the family) -------------------------------------------
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
