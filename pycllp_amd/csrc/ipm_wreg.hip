@@ -1642,7 +1642,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 struct WVariant { int mb, nq; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_solve_hsd<MB, NQ>, do_newton<MB, NQ> }
 // ordered by cost; the first variant with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(8, 4), WVARIANT(8, 6) };
+const WVariant kWVariants[] = { WVARIANT(8, 4), WVARIANT(8, 6), WVARIANT(8, 8) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace

@@ -798,6 +798,24 @@ def test_sparse_wave_and_block_kernels_agree():
         assert rel_err(w.primal_obj, k.primal_obj).max() < 1e-9 and rel_err(w.dual_obj, k.dual_obj).max() < 1e-9
 
 
+@pytest.mark.parametrize("m,n,variant", [(48, 200, "n <= 256"), (100, 280, "n <= 384"), (60, 440, "n <= 512")])
+def test_sparse_wave_kernel_column_variants(m, n, variant):
+    """The register-resident kernel is compiled for 4, 6 and 8 N-vector registers per lane (N <= 256, 384, 512 columns of the
+    equality form): one shape per variant, on the wave kernel, against the oracle LP by LP."""
+    A, b, c = problems.random_sparse_arrays(m, n, 24, density=0.02, seed=5)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    assert lp.ncols == m + n
+    for hsd in (False, True):
+        s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
+        lp.init(s)
+        st = lp.solve(s)
+        assert s.launch_info()["kernel"] == "wave", variant
+        r = oracle_on(lp, flags=32 if hsd else 0)
+        np.testing.assert_array_equal(st, r["status"])
+        assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+        assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+
+
 def test_sparse_config5_full_share_properties():
     """BASELINE configs[4], the full per-GPU share (16 384 LPs, shared sparse A 128 x 256): size-independent properties, as
     test_full_size_batch_properties does for configs[2] -- every LP optimal, KKT residuals, zero gap, bit-identical
