@@ -347,15 +347,18 @@ struct WReg {
     // padded rows get 1: identity rows of M) from the same pass over the row.  Four slots of both rows per round trip.
     template <bool DIAG>
     __device__ __forceinline__ void Arow(const double* v, double (&out)[MR], double (&md)[MR]) const {
-        static_assert(MR == 2, "two rows per lane");
+        static_assert(MR == 1 || MR == 2, "one or two rows per lane");
         unsigned pl[4];
         pin();
         {
-            const unsigned pa[4] = {lds_addr(csr_ptr + lane), lds_addr(csr_ptr + lane + 64), lds_addr(csr_len + lane), lds_addr(csr_len + lane + 64)};
+            // (MR == 1: the second row slot is a copy of the first with length 0 -- its loads are masked)
+            const int l2 = lane + (MR == 2 ? 64 : 0);
+            const unsigned pa[4] = {lds_addr(csr_ptr + lane), lds_addr(csr_ptr + l2), lds_addr(csr_len + lane), lds_addr(csr_len + l2)};
             lds_gather4_u16(pa, pl);
+            if (MR == 1) pl[3] = 0;
         }
         const unsigned vb = lds_addr(v), cvb = lds_addr(csr_val), ccb = lds_addr(csr_col);
-        double o0[MR] = {0.0, 0.0}, o1[MR] = {0.0, 0.0}, m0[MR] = {0.0, 0.0}, m1[MR] = {0.0, 0.0};
+        double o0[2] = {0.0, 0.0}, o1[2] = {0.0, 0.0}, m0[2] = {0.0, 0.0}, m1[2] = {0.0, 0.0};
         for (int t0 = 0; t0 < rmax; t0 += 4) {
             double2_t av[4]; unsigned cc[8], ga[8]; double a[8], xv[8], dv[8];
             lds_rows4x2(cvb + 8 * (pl[0] + t0), ccb + 2 * (pl[0] + t0), cvb + 8 * (pl[1] + t0), ccb + 2 * (pl[1] + t0), av, cc);
@@ -441,14 +444,14 @@ struct WReg {
     // parked in the accumulator file; the diagonal blocks (lower triangle with diagonal, packed by rows) are left in their
     // slots of the W area, where factor() picks block K up when its turn comes and then overwrites it with W_K.
     __device__ __forceinline__ void gram(const double (&Md)[MR]) {
-        static_assert(HB * 256 <= STAGE_D + MB * WL, "staging area too small");
-        static_assert((MB * WL) % 128 == 0, "diagonal-block slots are zeroed in whole b128 wavefront stores");
+        static_assert((G::NBLK < HB ? G::NBLK : HB) * 256 <= STAGE_D + MB * WL, "staging area too small");
         const double2_t zero = {0.0, 0.0};
         // zero the diagonal-block slots, scatter group g's diagonal-block entries (dsts relative to `base`), set the diagonal
         // from Md (row 16K + i lives in lane (16K + i) % 64 of register (16K + i) / 64)
         auto zero_slots = [&]() {
 #pragma unroll
-            for (int w = 0; w < (MB * WL) / 128; w++) ((double2_t*)wl_())[w * 64 + lane] = zero;
+            for (int w = 0; w < (MB * WL + 127) / 128; w++)
+                if ((w + 1) * 128 <= MB * WL || 2 * (w * 64 + lane) < MB * WL) ((double2_t*)wl_())[w * 64 + lane] = zero;
         };
         auto set_diag = [&]() {
 #pragma unroll
@@ -470,15 +473,17 @@ struct WReg {
             scatter_group(stage_(), ci);
             if constexpr (with_diag) set_diag();
             wave_lds_sync();
-            static_assert(nb % 4 == 0, "block loads go four blocks (16 registers) at a time");
+            // four blocks (16 registers) per round trip; a last group of fewer reads on into whatever follows in LDS and drops it
 #pragma unroll
             for (int b4 = 0; b4 < nb; b4 += 4) {
                 double v[16];
                 lds_run16<0, 512>(lds_addr(stage_() + b4 * 256 + lane), v);
 #pragma unroll
                 for (int bi = 0; bi < 4; bi++) {
-                    const double4_t blk = {v[4 * bi], v[4 * bi + 1], v[4 * bi + 2], v[4 * bi + 3]};
-                    park(P[b0 + b4 + bi], blk);
+                    if (b4 + bi < nb) {
+                        const double4_t blk = {v[4 * bi], v[4 * bi + 1], v[4 * bi + 2], v[4 * bi + 3]};
+                        park(P[b0 + b4 + bi], blk);
+                    }
                 }
             }
             wave_lds_sync();
@@ -1642,7 +1647,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 struct WVariant { int mb, nq; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_solve_hsd<MB, NQ>, do_newton<MB, NQ> }
 // ordered by cost; the first variant with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(8, 4), WVARIANT(8, 6), WVARIANT(8, 8) };
+const WVariant kWVariants[] = { WVARIANT(4, 2), WVARIANT(4, 4), WVARIANT(8, 4), WVARIANT(8, 6), WVARIANT(8, 8) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace
@@ -1833,6 +1838,9 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* b, const double*
     hipError_t e = hipMemsetAsync(defer, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     long cus = (long)num_cu - o.reserve_cus > 0 ? (long)num_cu - o.reserve_cus : 1;
+    // the m <= 64 variants need fewer than half the registers (234 of 512 per lane): two workgroups per CU -- two waves per
+    // SIMD -- where the LDS allows it
+    if (p->mb <= 4 && 2 * (long)p->tab.lds_bytes <= 160 * 1024) cus *= 2;
     long grid = std::min(cus, (B + 3) / 4);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
