@@ -75,7 +75,7 @@ def random_sparse_arrays(m, n, nproblems, density=0.025, seed=0):
     rs = np.random.RandomState(seed)
     A = sp.random(m, n, density=density, random_state=rs, format="lil")
     for i in range(m):
-        need = 3 - len(A.rows[i])
+        need = min(3, n) - len(A.rows[i])
         while need > 0:
             j = int(rs.randint(n))
             if A[i, j] == 0:

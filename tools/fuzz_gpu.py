@@ -55,10 +55,10 @@ check("equality LP, mixed-sign A, strictly feasible pair", s, st, port.dense_sol
 # sparse, random shapes
 for t in range(int(os.environ.get("FUZZ_NS", 8))):
     m = int(rs.randint(2, 129)); n = int(rs.randint(2, 513 - m)); B = int(rs.choice([1, 5, 40]))
-    dens = float(rs.choice([0.02, 0.05, 0.2]))
-    A, b, c = problems.random_sparse_arrays(m, n, B, density=max(dens, 3.0 / n), seed=int(rs.randint(1 << 30)))
+    dens = float(rs.choice([0.01, 0.02, 0.05, 0.2]))
+    A, b, c = problems.random_sparse_arrays(m, n, B, density=min(1.0, max(dens, 3.0 / n)), seed=int(rs.randint(1 << 30)))
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
     s = solver_registry["hip_sparse_primal_normal"](hsd=HSD); lp.init(s); st = lp.solve(s)
     r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8, flags=OFL)
-    check("sparse m=%d n=%d B=%d density %.2f nnz %d" % (m, n, B, dens, A.nnz), s, st, r)
+    check("sparse m=%d n=%d B=%d density %.2f nnz %d [%s]" % (m, n, B, dens, A.nnz, s.launch_info()["kernel"]), s, st, r)
 print("mismatches:", bad)
