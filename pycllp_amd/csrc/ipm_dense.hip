@@ -1098,7 +1098,9 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     BlockA desc = h->desc;
     int lds = h->lds;
     if (a_batch) { desc.a_in_lds = 1; lds = h->lds_with_a; }
-    const bool use_wreg = !a_batch && h->wreg && !(o.flags & (PYCLLP_FLAG_BLOCK_KERNEL | PYCLLP_FLAG_AUTOSCALE));
+    // (autoscale exists in the plain wave kernel; with HSD it runs on the block kernel)
+    const bool use_wreg = !a_batch && h->wreg && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL) &&
+                          !((o.flags & PYCLLP_FLAG_AUTOSCALE) && (o.flags & PYCLLP_FLAG_HSD));
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
         HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));

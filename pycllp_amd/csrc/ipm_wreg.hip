@@ -849,6 +849,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     const int& lane = w.lane;
     const int m = w.m, n = w.n;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+    const bool autoscale = (o.flags & PYCLLP_FLAG_AUTOSCALE) != 0;
     const double nm = (double)(n + m);
     double* vx = w.stage_();
     bool okc[NQ], okr[MR];
@@ -868,23 +869,40 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         double x[NQ], z[NQ];
         double c2 = 0.0;
         const __amdgpu_buffer_rsrc_t rc = row_rsrc(cg + lp * n, n), rx = row_rsrc(xg + lp * n, n), rz = row_rsrc(zg ? zg + lp * n : nullptr, n);
+        // PYCLLP_FLAG_AUTOSCALE: the LP is solved with b / max|b| and c / max|c| (the same divisions as ipm_block_kernel and
+        // the oracle), undone when storing
+        double sb = 1.0, sc = 1.0;
+        if (autoscale) {
+            double cm = 0.0, bm = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) cm = fmax(cm, fabs(buf_ld(rc, w.coff(qq))));
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) bm = fmax(bm, okr[r2] ? fabs(bg[lp * m + lane + 64 * r2]) : 0.0);
+            sb = wmax(bm); sc = wmax(cm);
+            sb = uni((sb > 0.0) ? sb : 1.0); sc = uni((sc > 0.0) ? sc : 1.0);
+        }
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             const unsigned jo = w.coff(qq);
-            const double cj = buf_ld(rc, jo);
+            double cj = buf_ld(rc, jo);
+            if (autoscale) cj = cj / sc;
             c2 = fma(cj, cj, c2);
             x[qq] = (warm && okc[qq]) ? buf_ld(rx, jo) : 1.0;
             z[qq] = (warm && okc[qq]) ? buf_ld(rz, jo) : 1.0;
+            if (autoscale && warm) { x[qq] = x[qq] / sb; z[qq] = z[qq] / sc; }
         }
         double b2 = 0.0;
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) {
             const int i = lane + 64 * r2;
-            const double bi = okr[r2] ? bg[lp * m + i] : 0.0;
+            double bi = okr[r2] ? bg[lp * m + i] : 0.0;
+            if (autoscale) bi = bi / sb;
             b2 = fma(bi, bi, b2);
             if (i < MP) {
+                double yi = okr[r2] ? ((warm && yg) ? yg[lp * m + i] : 1.0) : 0.0;
+                if (autoscale && warm && yg) yi = yi / sc;
                 w.bs_()[i] = bi;
-                w.ys_()[i] = okr[r2] ? ((warm && yg) ? yg[lp * m + i] : 1.0) : 0.0;
+                w.ys_()[i] = yi;
             }
         }
         wave_lds_sync();
@@ -925,6 +943,10 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
                 for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
                 w.At(w.ys_(), v);
+                if (autoscale) {
+#pragma unroll
+                    for (int qq = 0; qq < NQ; qq++) cq[qq] = cq[qq] / sc;
+                }
 #pragma unroll
                 for (int qq = 0; qq < NQ; qq++) {
                     cv[qq] = okc[qq] ? cq[qq] - v[qq] : 0.0;
@@ -1058,16 +1080,16 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {      // (padded positions and a null z: dropped)
                 const unsigned jo = w.coff(qq);
-                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq]); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq]);
+                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq] * sb); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq] * sc);
             }
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i];
+                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i] * sc;
             }
             if (lane == 0) {
-                if (pobj) pobj[lp] = po;
-                if (dobj) dobj[lp] = du;
+                if (pobj) pobj[lp] = po * (sb * sc);
+                if (dobj) dobj[lp] = du * (sb * sc);
                 status[lp] = stat;
                 if (iters) iters[lp] = it;
             }
