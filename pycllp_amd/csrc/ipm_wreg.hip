@@ -11,23 +11,27 @@
 // four wavefronts and pays for it in barriers, in waves idling during the serial pivot chain and the triangular solves
 // (44 % + 26 % of its run time), and in SIMDs idling.  The register file of a CU is 512 KB -- three times its LDS.  Here
 // each of the 4 SIMDs of a CU runs one wavefront with the full 512-register budget that owns one LP:
-//   * the factor is kept as U = L' in 16 x 16 blocks U[K][I] (K <= I) in the ACCUMULATOR layout of
-//     v_mfma_f64_16x16x4_f64 (register r of lane l holds element [4r + (l >> 4)][l & 15]): 36 blocks x 4 doubles at
-//     m = 128 (see below: 28 of them resident).  That layout is, unchanged, the B operand of the block and the A operand of its transpose, so both the
-//     panel solve  Y_KI = L_KK^-1 M_KI  and the trailing update  U_JI -= Y_KJ' U_KI  are MFMAs straight on the resident
-//     registers -- no operand ever moves;
-//   * only the 28 OFF-DIAGONAL blocks live in registers (224 of the 256 accumulator registers).  A diagonal block is
-//     formed when its turn comes (left-looking): its Schur update on the matrix cores, plus the original block straight
-//     from the tables, into a 2 KB LDS tile; from there it is read in "lane = row" form and factored by a 16-step DPP
-//     (row_newbcast) chain -- every 16-lane row of the wave redundantly, so nothing is broadcast across rows -- and its
-//     inverse W_K = L_KK^-1 is formed directly in the MFMA A-operand layout (quad q owns columns q, q+4, ...) for the
-//     panel; W_K is also what the triangular solves use, from a packed copy in LDS (1 KB per block);
-//   * M = A diag(x/z) A' is assembled from entry/term tables built once at init (deterministic, atomic-free),
-//     scattered through a 8 KB LDS stage one block column at a time and loaded in the accumulator layout;
-//   * A x and A'u use ELL copies of A (by rows / by columns) in LDS; N-vectors live in registers (lane = column),
-//     m-vectors in a per-wave LDS area;
+//   * the factor is kept as U = L' in 16 x 16 blocks U[K][I] (K < I) in the ACCUMULATOR layout of
+//     v_mfma_f64_16x16x4_f64 (register r of lane l holds element [4r + (l >> 4)][l & 15]).  That layout is, unchanged, the
+//     B operand of the block and the A operand of its transpose, so both the panel solve  Y_KI = L_KK^-1 M_KI  and the
+//     trailing update  U_JI -= Y_KJ' U_KI  are MFMAs straight on the resident registers -- no operand ever moves;
+//   * only the OFF-DIAGONAL blocks live in registers (m = 128: 28 blocks = 224 of the 256 accumulator registers).  A
+//     diagonal block is formed when its turn comes (left-looking): its Schur update on the matrix cores into a 2 KB LDS
+//     tile, plus the original block, which the Gram pass left in the block's W slot; it is read in "lane = row" form and
+//     factored by a 16-step chain of fused 64-bit DPP FMAs (v_fmac_f64_dpp row_newbcast) -- every 16-lane row of the wave
+//     redundantly, so nothing is broadcast across rows -- and its inverse W_K = L_KK^-1 is formed directly in the MFMA
+//     A-operand layout (quad q owns columns q, q+4, ...) for the panel; W_K is also what the triangular solves use, from a
+//     packed copy in LDS (the slot of the original block);
+//   * M = A diag(x/z) A' is assembled from flat term records built once at init (deterministic, atomic-free, no inner
+//     loop: first terms of all entries, then triples of further terms), scattered through a 16 KB staging area 8 blocks
+//     at a time and loaded in the accumulator layout;
+//   * A x and A'u use compact-CSR / JDS-ELL copies of A in LDS; N-vectors live in registers (lane = column) while they
+//     are worked on and in LDS across the factorisation and the loop's back edge, m-vectors in a per-wave LDS area;
+//   * LDS reads come in inline-asm batches (N reads, one s_waitcnt) and every lane-dependent address is derived from
+//     three pinned values where it is used (WReg::pin): no scratch traffic inside the iteration loop;
 //   * the triangular solves are 16-row block steps: 4 FMAs per off-diagonal block, quad/row reductions by
 //     v_permlane swaps and DPP.
+// Variants (MB 16-row blocks, NQ 64-column N-vector registers): (4,2) (4,4) (8,4) (8,6) (8,8); see kWVariants.
 // The Nocedal-Wright guard (ldl.cl:487) is not applied here: the sweep records whether it WOULD have bitten and such an
 // LP (never seen on a positive definite M) is deferred to ipm_block_kernel, which applies it exactly.
 // Semantics = oracle/ipm_dense_ref.c (ipm_one_path / hsd_one_raw), like every other kernel of this library.
@@ -300,7 +304,7 @@ struct WReg {
     // arithmetic of all of them folds into a handful of lane-dependent bases plus immediate offsets (as separate
     // run-time pointers every (array, index pattern) pair costs a VGPR for the whole kernel)
     double* W0;
-    __device__ __forceinline__ double* stage_() const { return W0; }                            // [STAGE_D] Gram staging; aliases: vx = stage_()[0..NP), tile, rr
+    __device__ __forceinline__ double* stage_() const { return W0; }                            // [STAGE_D] N-vector staging (vx = stage_()[0..NP)), parked x / z, tile; with wl_(): the Gram staging area
     __device__ __forceinline__ double* wl_() const { return W0 + STAGE_D; }                     // [MB][WL] diagonal-block slots (see WL); with the stage in front of it: the Gram staging area
     __device__ __forceinline__ double* vd_() const { return W0 + STAGE_D + MB * WL; }           // [NP] d = x/z
     __device__ __forceinline__ double* ys_() const { return W0 + STAGE_D + MB * WL + NP; }                // [MP] y
