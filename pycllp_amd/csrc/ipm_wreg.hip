@@ -111,6 +111,10 @@ struct WregTab {
     int o_csr_val, o_ec_val, o_t_w, o_wave, o_lev, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
         o_t_cd;                                           // LDS byte offsets
     int wave_doubles, lds_bytes;
+    // dense variant (DA): no tables, A as a row-major image [img_rows][as] of its first nd columns (the remaining n - nd
+    // columns are the identity, column nd + i = e_i, or there are none), as = nd rounded up to 8, + 1
+    int nd, as, img_rows, o_img, wpb;
+    const double* img;
 };
 
 // ---- cross-lane helpers ----------------------------------------------------------------------------------------
@@ -285,7 +289,7 @@ __device__ __forceinline__ void lds_terms3(unsigned aw, unsigned ac, double (&w)
 }
 
 // ---- the per-wave machinery ------------------------------------------------------------------------------------
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA = false>
 struct WReg {
     using G = WGeo<MB>;
     static constexpr int MP = G::MP, MR = G::MR, MPL = G::MPL, NP = 64 * NQ, STAGE_D = stage_d(NQ), TILE_OFF = tile_off(NQ);
@@ -300,6 +304,8 @@ struct WReg {
     const double* ec_val; const unsigned short* ec_row; const unsigned* colmap;
     const double* t_w; const unsigned* t_cd; const int* lev;
     const int* meta;
+    // DA: the dense image (LDS), its row stride and the number of dense columns; n_sl = n - nd identity columns behind them
+    const double* img; int nd, AS, imgR;
     // LDS: this wave's area, every array at a COMPILE-TIME offset from the one base pointer W0 -- so that the address
     // arithmetic of all of them folds into a handful of lane-dependent bases plus immediate offsets (as separate
     // run-time pointers every (array, index pattern) pair costs a VGPR for the whole kernel)
@@ -319,13 +325,42 @@ struct WReg {
     // registers to spill; pin() makes the three values opaque at the point of the call, so that what is derived from them
     // below is recomputed there (a VALU instruction or two) and dies after its use.
     // byte offset inside an LP's row of the column at position lane + 64 qq of the N-vectors (PAD_OFF: padded position)
-    __device__ __forceinline__ unsigned coff(int qq) const { return colmap[lane + 64 * qq]; }
+    __device__ __forceinline__ unsigned coff(int qq) const {
+        if constexpr (DA) { const int p = lane + 64 * qq; return p < n ? 8u * (unsigned)p : PAD_OFF; }
+        else return colmap[lane + 64 * qq];
+    }
     __device__ __forceinline__ void pin() const { asm volatile("" : "+v"(lane), "+v"(q), "+v"(c16)); }
 
     // out_q = (A'u)_j for the column at position lane + 64 q (see colmap), u in LDS.  ELL: slot t of register q sits at
     // (coff_q + t) 64 + lane -- an immediate offset from one lane-dependent base; padded slots hold value 0, row 0.
     __device__ __forceinline__ void At(const double* u, double (&out)[NQ]) const {
         pin();
+        if constexpr (DA) {
+            // dense image: column p of the dense part is one image column (lanes read consecutive entries of a row: no bank
+            // conflict), u comes as broadcast reads; the identity columns behind them pick their own u_i
+            const unsigned ub = lds_addr(u), ib = lds_addr(img);
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                const int p = lane + 64 * qq;
+                double a0 = 0.0, a1 = 0.0;
+                if (64 * qq < nd) {
+                    const unsigned cb = ib + 8 * (unsigned)((p < nd) ? p : 0);
+                    for (int i0 = 0; i0 < imgR; i0 += 8) {
+                        unsigned ga[8]; double av[8], uv[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ga[k] = cb + 8 * (unsigned)((i0 + k) * AS);
+                        lds_gather8(ga, av);
+                        lds_run8<0, 8>(ub + 8 * i0, uv);
+#pragma unroll
+                        for (int k = 0; k < 8; k += 2) { a0 = fma(av[k], uv[k], a0); a1 = fma(av[k + 1], uv[k + 1], a1); }
+                    }
+                }
+                const bool sl = p >= nd && p < n;
+                const double us = u[sl ? p - nd : 0];
+                out[qq] = (p < nd) ? a0 + a1 : (sl ? us : 0.0);
+            }
+            return;
+        }
         const unsigned ub = lds_addr(u), vb = lds_addr(ec_val) + 8 * lane, rb = lds_addr(ec_row) + 2 * lane;
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
@@ -352,8 +387,37 @@ struct WReg {
     template <bool DIAG>
     __device__ __forceinline__ void Arow(const double* v, double (&out)[MR], double (&md)[MR]) const {
         static_assert(MR == 1 || MR == 2, "one or two rows per lane");
-        unsigned pl[4];
         pin();
+        if constexpr (DA) {
+            // row i of the image (odd stride: conflict free across the lanes) against broadcast reads of v (and d); the
+            // identity column of row i adds v[nd + i] (and d[nd + i] to the diagonal)
+            const unsigned vb = lds_addr(v), ib = lds_addr(img);
+            const bool has_sl = n > nd;
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) {
+                const int i = lane + 64 * r2;
+                const bool rok = i < m;
+                const unsigned rb = ib + 8 * (unsigned)((rok ? i : 0) * AS);
+                double o0 = 0.0, o1 = 0.0, m0 = 0.0, m1 = 0.0;
+                for (int j0 = 0; j0 + 1 < AS; j0 += 8) {
+                    double a[8], xv[8], dv[8];
+                    lds_run8<0, 8>(rb + 8 * j0, a);
+                    lds_run8<0, 8>(vb + 8 * j0, xv);
+                    if (DIAG) lds_run8<8 * (STAGE_D + MB * WL), 8>(vb + 8 * j0, dv);
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        o0 = fma(a[k], xv[k], o0); o1 = fma(a[k + 1], xv[k + 1], o1);
+                        if (DIAG) { m0 = fma(a[k] * a[k], dv[k], m0); m1 = fma(a[k + 1] * a[k + 1], dv[k + 1], m1); }
+                    }
+                }
+                const int js = (rok && has_sl) ? nd + i : 0;
+                const double vs = v[js], ds = DIAG ? vd_()[js] : 0.0;
+                out[r2] = rok ? (o0 + o1) + (has_sl ? vs : 0.0) : 0.0;
+                md[r2] = DIAG ? (rok ? (m0 + m1) + (has_sl ? ds : 0.0) : 1.0) : 0.0;
+            }
+            return;
+        }
+        unsigned pl[4];
         {
             // (MR == 1: the second row slot is a copy of the first with length 0 -- its loads are masked)
             const int l2 = lane + (MR == 2 ? 64 : 0);
@@ -448,6 +512,7 @@ struct WReg {
     // parked in the accumulator file; the diagonal blocks (lower triangle with diagonal, packed by rows) are left in their
     // slots of the W area, where factor() picks block K up when its turn comes and then overwrites it with W_K.
     __device__ __forceinline__ void gram(const double (&Md)[MR]) {
+        if constexpr (DA) { gram_dense(Md); return; }
         static_assert((G::NBLK < HB ? G::NBLK : HB) * 256 <= STAGE_D + MB * WL, "staging area too small");
         const double2_t zero = {0.0, 0.0};
         // zero the diagonal-block slots, scatter group g's diagonal-block entries (dsts relative to `base`), set the diagonal
@@ -500,6 +565,84 @@ struct WReg {
             set_diag();
             wave_lds_sync();
         }
+    }
+
+    // Dense image variant of gram(): M = (A diag(d)) A' block by block on the matrix cores, k = the dense columns four at a
+    // time.  Operands straight from the image: A-operand lane (m = c16, k = q) = A[16K + c16][4s + q] d[4s + q], B-operand
+    // lane (k = q, n = c16) = A[16I + c16][4s + q]; the accumulator of block (K, I) IS the block in the layout it is kept
+    // in.  All off-diagonal accumulators are live through one pass over the columns (NBLK x 8 accumulator registers); the
+    // diagonal blocks take a second pass and go, lower triangle packed by rows, to their W slots like in gram().
+    __device__ __forceinline__ void gram_dense(const double (&Md)[MR]) {
+        pin();
+        const unsigned ib = lds_addr(img), db = lds_addr(vd_()) + 8 * q;
+        unsigned ra[MB]; bool rok[MB];
+#pragma unroll
+        for (int J = 0; J < MB; J++) {
+            const int r = 16 * J + c16;
+            rok[J] = r < imgR;
+            ra[J] = ib + 8 * (unsigned)((rok[J] ? r : 0) * AS + q);
+        }
+        const int ks = (AS - 1) / 4;
+        // (at most 14 off-diagonal accumulators per pass over the columns: with all 28 of m = 128 live next to the blocks
+        // already parked the register file overflows)
+        constexpr int PB = 14, NPASS = (G::NBLK + PB - 1) / PB;
+        static_for<0, NPASS>([&](auto Hc) {
+            constexpr int b0 = PB * decltype(Hc)::value, b1 = (b0 + PB < G::NBLK) ? b0 + PB : G::NBLK;
+            double4_t acc[PB];
+#pragma unroll
+            for (int b = 0; b < PB; b++) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int s = 0; s < ks; s++) {
+                double a[MB], ad[MB];
+                const double dk = *(const __attribute__((address_space(3))) double*)(size_t)(db + 32 * s);
+#pragma unroll
+                for (int J = 0; J < MB; J++) {
+                    const double v = *(const __attribute__((address_space(3))) double*)(size_t)(ra[J] + 32 * s);
+                    a[J] = rok[J] ? v : 0.0;
+                    ad[J] = a[J] * dk;
+                }
+                static_for<0, MB>([&](auto Kc) {
+                    constexpr int K = decltype(Kc)::value;
+                    static_for<K + 1, MB>([&](auto Ic) {
+                        constexpr int I = decltype(Ic)::value;
+                        constexpr int bx = G::bix(K, I);
+                        if constexpr (bx >= b0 && bx < b1)
+                            acc[bx - b0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[K], a[I], acc[bx - b0], 0, 0, 0);
+                    });
+                });
+            }
+#pragma unroll
+            for (int b = b0; b < b1; b++) park(P[b], acc[b - b0]);
+        });
+        double4_t dacc[MB];
+#pragma unroll
+        for (int K = 0; K < MB; K++) dacc[K] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int s = 0; s < ks; s++) {
+            const double dk = *(const __attribute__((address_space(3))) double*)(size_t)(db + 32 * s);
+#pragma unroll
+            for (int J = 0; J < MB; J++) {
+                const double v = *(const __attribute__((address_space(3))) double*)(size_t)(ra[J] + 32 * s);
+                const double a = rok[J] ? v : 0.0;
+                dacc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * dk, a, dacc[J], 0, 0, 0);
+            }
+        }
+        // accumulator register r of lane (q, c16) = element [row 4r + q][column c16] of the block: lower triangle (with the
+        // diagonal, which set below from Md) to offset row (row + 1) / 2 + column of slot K, the rest to the slot's spare doubles
+#pragma unroll
+        for (int K = 0; K < MB; K++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * r + q;
+                wl_()[K * WL + ((c16 <= row) ? row * (row + 1) / 2 + c16 : 138 + r)] = dacc[K][r];
+            }
+        wave_lds_sync();
+#pragma unroll
+        for (int r2 = 0; r2 < MR; r2++) {
+            const int row = lane + 64 * r2, il = row & 15;
+            if (row < MP) wl_()[(row >> 4) * WL + il * (il + 1) / 2 + il] = Md[r2];
+        }
+        wave_lds_sync();
     }
 
     // W_K element [row 4s + q][column c16] -- the TRANSPOSED operand layout -- from the packed copy in LDS
@@ -720,16 +863,26 @@ struct WReg {
     }
 };
 
-template <int MB, int NQ>
-__device__ __forceinline__ void wreg_carve(WReg<MB, NQ>& w, double* W0, int tid) {
+template <int MB, int NQ, bool DA>
+__device__ __forceinline__ void wreg_carve(WReg<MB, NQ, DA>& w, double* W0, int tid) {
     using G = WGeo<MB>;
     w.W0 = W0;
     w.lane = tid & 63; w.q = w.lane >> 4; w.c16 = w.lane & 15;
 }
 
-template <int MB, int NQ>
-__device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, unsigned char* lraw, int tid) {
+template <int MB, int NQ, bool DA>
+__device__ __forceinline__ void wreg_setup(WReg<MB, NQ, DA>& w, const WregTab& T, unsigned char* lraw, int tid) {
     using G = WGeo<MB>;
+    if constexpr (DA) {
+        double* s_img = (double*)(lraw + T.o_img);
+        const int cnt = T.img_rows * T.as;
+        for (int i = tid; i < cnt; i += (int)blockDim.x) s_img[i] = T.img[i];
+        __syncthreads();
+        w.img = s_img; w.nd = T.nd; w.AS = T.as; w.imgR = T.img_rows;
+        wreg_carve(w, (double*)(lraw + T.o_wave) + (size_t)(tid >> 6) * T.wave_doubles, tid);
+        w.m = T.m; w.n = T.n; w.rmax = 0;
+        return;
+    }
     double* s_csr_val = (double*)(lraw + T.o_csr_val);
     double* s_ec_val = (double*)(lraw + T.o_ec_val);
     double* s_t_w = (double*)(lraw + T.o_t_w);
@@ -767,8 +920,8 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ>& w, const WregTab& T, un
 // TCV: the caller has parked x and z in the stage (at NP, 2 NP) and cv = c - A'y in vd_() in place of d; t = cv + mu / x and
 // d = x / z are formed here (the same expressions the caller used for the right-hand side).
 // Out: dy (per row), dx, wv = A'dy, e = rho - A dx.  Returns the refinement passes used; `bad` reports a non-finite dy.
-template <bool TCV, int MB, int NQ>
-__device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
+template <bool TCV, int MB, int NQ, bool DA>
+__device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
                                             const double (&rho)[WGeo<MB>::MR], double etol, int max_refine, double mu,
                                             double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ],
                                             double (&e)[WGeo<MB>::MR], bool& bad STAMP_ARGS) {
@@ -838,7 +991,7 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ>& w, const bool (&okc)[N
 // ------------------------------------------------------------------------------------------------------------------
 // solve kernel: sparse_standard_primal_normal (primal_normal.cl:287-375), one LP per wavefront
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 __global__ void __launch_bounds__(256, 1)
 ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg,
                 double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
@@ -847,7 +1000,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     using G = WGeo<MB>;
     constexpr int MR = G::MR, MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
-    WReg<MB, NQ> w;
+    WReg<MB, NQ, DA> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int& lane = w.lane;
@@ -1111,7 +1264,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 // branch, csrc/ipm_group_hsd.inc): tau and kappa are wave-uniform scalars, one factorisation serves the two right-hand
 // sides  M p = A(d c) - b  and  M q = A(d r1) - eta rho, the pivot floor of column j is pivot_floor^2 |M_jj|
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 __global__ void __launch_bounds__(256, 1)
 hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg,
                 double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
@@ -1120,7 +1273,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     using G = WGeo<MB>;
     constexpr int MR = G::MR, MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
-    WReg<MB, NQ> w;
+    WReg<MB, NQ, DA> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int& lane = w.lane;
@@ -1448,7 +1601,7 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 // stand-alone Newton step: sparse_solve_primal_normal (ldl.cl:656-712) as launched by the reference's
 // tests/test_ldl.py:276-361, one state per wavefront
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 __global__ void __launch_bounds__(256, 1)
 newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const double* __restrict__ zg,
                    const double* __restrict__ yg, const double* __restrict__ bg, const double* __restrict__ cg, double mu,
@@ -1456,7 +1609,7 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
     using G = WGeo<MB>;
     constexpr int MR = G::MR, MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
-    WReg<MB, NQ> w;
+    WReg<MB, NQ, DA> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int& lane = w.lane; const int m = w.m, n = w.n;
@@ -1622,6 +1775,7 @@ __global__ void wreg_selftest_kernel(double* out) {
 struct WregPlan {
     WregTab tab;
     int mb, nq;
+    bool da = false;
     void* dev_blob;
 };
 
@@ -1640,49 +1794,104 @@ typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const doubl
 typedef hipError_t (*wnewton_fn)(const WregTab&, long, const double*, const double*, const double*, const double*,
                                  const double*, double, double*, int*, int*, DevOpts, int, hipStream_t);
 
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 hipError_t do_solve(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
                     double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                     hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)ipm_wreg_kernel<MB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)ipm_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ>), dim3(grid), dim3(256), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
     return hipGetLastError();
 }
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 hipError_t do_solve_hsd(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
                         double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                         hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)hsd_wreg_kernel<MB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)hsd_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ>), dim3(grid), dim3(256), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
     return hipGetLastError();
 }
-template <int MB, int NQ>
+template <int MB, int NQ, bool DA>
 hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z, const double* y, const double* b,
                      const double* c, double mu, double* dy, int* nref, int* qhead, DevOpts o, int grid, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)newton_wreg_kernel<MB, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)newton_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((newton_wreg_kernel<MB, NQ>), dim3(grid), dim3(256), T.lds_bytes, st, T, B, x, z, y, b, c, mu, dy,
+    hipLaunchKernelGGL((newton_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, x, z, y, b, c, mu, dy,
                        nref, qhead, o);
     return hipGetLastError();
 }
 
-struct WVariant { int mb, nq; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
-#define WVARIANT(MB, NQ) { MB, NQ, do_solve<MB, NQ>, do_solve_hsd<MB, NQ>, do_newton<MB, NQ> }
-// ordered by cost; the first variant with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(4, 2), WVARIANT(4, 4), WVARIANT(8, 4), WVARIANT(8, 6), WVARIANT(8, 8) };
+struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
+#define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
+// ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
+const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false),
+                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace
 
-int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
-                     hipStream_t st, WregPlan** out) {
+// Plan with A as a dense image in LDS (no tables): for matrices whose Gram term list does not fit -- dense A's, e.g. the LPs
+// hip_dense_primal_normal hands over beyond m = 32.  The last m columns are kept out of the image when they are the
+// identity (equality form of a StandardLP).  Fewer than four waves per workgroup when that is what lets the image fit.
+static int wreg_plan_create_dense(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+                                  hipStream_t st, WregPlan** out) {
     int vi = -1;
     for (int i = 0; i < kNumWVariants; i++)
-        if (m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
+        if (kWVariants[i].da && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
+    if (vi < 0) return 1;
+    const int MB = kWVariants[vi].mb, NQ = kWVariants[vi].nq, MP = 16 * MB;
+    // identity tail?
+    bool sl = n > m;
+    std::vector<int> tail_cnt(sl ? m : 0, 0);
+    for (int i = 0; i < m && sl; i++)
+        for (int e = ptr[i]; e < ptr[i + 1]; e++)
+            if (col[e] >= n - m) { if (col[e] != n - m + i || val[e] != 1.0) sl = false; else tail_cnt[i]++; }
+    for (int i = 0; i < m && sl; i++) if (tail_cnt[i] != 1) sl = false;
+    const int nd = sl ? n - m : n, ndp = ((std::max(nd, 1) + 7) / 8) * 8, AS = ndp + 1, R = ((m + 7) / 8) * 8;
+    WregPlan* P = new WregPlan();
+    WregTab& T = P->tab;
+    memset(&T, 0, sizeof(T));
+    T.m = m; T.n = n; T.nnz = nnz; T.nd = nd; T.as = AS; T.img_rows = R;
+    T.wave_doubles = stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL;
+    const size_t img_bytes = sizeof(double) * (size_t)R * AS;
+    int wpb = 0;
+    for (int w = 4; w >= 1; w--)
+        if (img_bytes + 16 + sizeof(double) * (size_t)w * T.wave_doubles <= (size_t)max_lds) { wpb = w; break; }
+    if (!wpb) { delete P; return 1; }
+    T.wpb = wpb; T.o_img = 0; T.o_wave = (int)((img_bytes + 15) & ~(size_t)15);
+    T.lds_bytes = T.o_wave + (int)(sizeof(double) * (size_t)wpb * T.wave_doubles);
+    std::vector<double> img((size_t)R * AS, 0.0);
+    for (int i = 0; i < m; i++)
+        for (int e = ptr[i]; e < ptr[i + 1]; e++)
+            if (col[e] < nd) img[(size_t)i * AS + col[e]] = val[e];
+    hipError_t e = hipMalloc(&P->dev_blob, img.size() * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { if (P->dev_blob) (void)hipFree(P->dev_blob); delete P; return 1000 + (int)e; }
+    T.img = (const double*)P->dev_blob;
+    P->mb = MB; P->nq = NQ; P->da = true;
+    *out = P;
+    return 0;
+}
+
+static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+                                   hipStream_t st, WregPlan** out);
+
+int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+                     hipStream_t st, WregPlan** out) {
+    const int rc = wreg_plan_create_tables(m, n, nnz, val, ptr, col, max_lds, st, out);
+    if (rc != 1) return rc;
+    return wreg_plan_create_dense(m, n, nnz, val, ptr, col, max_lds, st, out);
+}
+
+static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+                                   hipStream_t st, WregPlan** out) {
+    int vi = -1;
+    for (int i = 0; i < kNumWVariants; i++)
+        if (!kWVariants[i].da && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
     if (vi < 0 || nnz >= 65536) return 1;
     const int MB = kWVariants[vi].mb, NQ = kWVariants[vi].nq;
     const int MP = 16 * MB, MPL = 64 * ((MP + 63) / 64), NP = 64 * NQ;
@@ -1837,7 +2046,7 @@ int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, c
     T.csr_len = (const unsigned short*)(db + a7); T.ec_row = (const unsigned short*)(db + a8);
     T.colmap = (const unsigned*)(db + a9);
     T.t_cd = (const unsigned*)(db + a11);
-    P->mb = MB; P->nq = NQ;
+    P->mb = MB; P->nq = NQ; T.wpb = 4;
     *out = P;
     return 0;
 }
@@ -1852,7 +2061,7 @@ int wreg_lds_bytes(const WregPlan* p) { return p ? p->tab.lds_bytes : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)
-        if (kWVariants[i].mb == p->mb && kWVariants[i].nq == p->nq) return &kWVariants[i];
+        if (kWVariants[i].mb == p->mb && kWVariants[i].nq == p->nq && kWVariants[i].da == p->da) return &kWVariants[i];
     return nullptr;
 }
 
@@ -1867,7 +2076,7 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* b, const double*
     // the m <= 64 variants need fewer than half the registers (234 of 512 per lane): two workgroups per CU -- two waves per
     // SIMD -- where the LDS allows it
     if (p->mb <= 4 && 2 * (long)p->tab.lds_bytes <= 160 * 1024) cus *= 2;
-    long grid = std::min(cus, (B + 3) / 4);
+    long grid = std::min(cus, (B + p->tab.wpb - 1) / p->tab.wpb);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
     return ((o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve)(p->tab, B, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
@@ -1881,7 +2090,7 @@ hipError_t wreg_launch_newton(WregPlan* p, long B, const double* x, const double
     hipError_t e = hipMallocAsync((void**)&qhead, sizeof(int), st);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(qhead, 0, sizeof(int), st);
-    long grid = std::min((long)num_cu, (B + 3) / 4);
+    long grid = std::min((long)num_cu, (B + p->tab.wpb - 1) / p->tab.wpb);
     if (grid < 1) grid = 1;
     if (e == hipSuccess) e = v->newton(p->tab, B, x, z, y, b, c, mu, dy, nref, qhead, o, (int)grid, st);
     hipError_t e2 = hipFreeAsync(qhead, st);
