@@ -816,6 +816,34 @@ def test_sparse_wave_kernel_column_variants(m, n, variant):
         assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("case", ["standard 64x64", "standard 100x80", "equality 40x100 without identity columns"])
+def test_dense_image_variant_of_the_wave_kernel(case):
+    """A matrix whose Gram term list does not fit into LDS but whose dense image does runs on the dense-image variant of the
+    register-resident kernel (MFMA Gram straight from the image, image mat-vecs): dense StandardLPs -- the identity columns of
+    the equality form stay out of the image -- and a dense EqualityLP that has none.  Against the oracle LP by LP."""
+    rs = np.random.RandomState(8)
+    if case.startswith("standard"):
+        m, n = (64, 64) if "64x64" in case else (100, 80)
+        A, b, c = problems.random_dense_arrays(m, n, 48, seed=m)
+        lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    else:
+        m, n, B = 40, 100, 48
+        A = rs.randn(m, n)
+        x0 = rs.rand(B, n) + 0.1; y0 = rs.randn(B, m)
+        b = x0 @ A.T; c = y0 @ A - (rs.rand(B, n) + 0.1)          # strictly feasible primal-dual pair
+        lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)
+    for hsd in (False, True):
+        s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
+        lp.init(s)
+        st = lp.solve(s)
+        assert s.launch_info()["kernel"] == "wave"
+        r = oracle_on(lp, flags=32 if hsd else 0)
+        np.testing.assert_array_equal(st, r["status"])
+        assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+        assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+        np.testing.assert_allclose(s.x, r["x"], rtol=1e-5, atol=1e-6)
+
+
 def test_sparse_config5_full_share_properties():
     """BASELINE configs[4], the full per-GPU share (16 384 LPs, shared sparse A 128 x 256): size-independent properties, as
     test_full_size_batch_properties does for configs[2] -- every LP optimal, KKT residuals, zero gap, bit-identical
