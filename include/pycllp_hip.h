@@ -177,8 +177,9 @@ int pycllp_hip_sparse_solve_batch(pycllp_hip_sparse *handle, long B, const doubl
 int pycllp_hip_sparse_newton(pycllp_hip_sparse *handle, long B, const double *x_dev, const double *z_dev,
                              const double *y_dev, const double *b_dev, const double *c_dev, double mu, double *dy_dev,
                              int *nrefine_dev, const pycllp_hip_opts *opts, void *stream);
-/* grid (workgroups), LDS bytes per workgroup and kernel (0 = workgroup-per-LP block kernel, 1 = register-resident
- * wavefront-per-LP kernel) of the last solve launch on this handle (host values; not thread-safe). */
+/* grid (workgroups), threads per workgroup, LDS bytes per workgroup and kernel (0 = workgroup-per-LP block kernel,
+ * 1 = register-resident wavefront-per-LP kernel on term tables, 2 = the same on a dense image of A) of the last solve
+ * launch on this handle (host values; not thread-safe). */
 int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse *handle, int *grid, int *block, int *lds_bytes, int *kernel);
 void pycllp_hip_sparse_free(pycllp_hip_sparse *handle);
 

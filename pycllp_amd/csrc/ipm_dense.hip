@@ -1188,9 +1188,9 @@ int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse* h, int* grid, int* bl
     if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_launch_info: bad argument");
     std::lock_guard<std::mutex> g(h->info_mu);
     if (grid) *grid = h->grid;
-    if (block) *block = BLK_T;
+    if (block) *block = h->last_wreg ? wreg_block_threads(h->wreg) : BLK_T;
     if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->wreg) : h->lds;
-    if (kernel) *kernel = h->last_wreg;
+    if (kernel) *kernel = h->last_wreg ? wreg_variant(h->wreg) : 0;
     return 0;
 }
 

@@ -2058,6 +2058,8 @@ void wreg_plan_free(WregPlan* p) {
 }
 
 int wreg_lds_bytes(const WregPlan* p) { return p ? p->tab.lds_bytes : 0; }
+int wreg_block_threads(const WregPlan* p) { return p ? 64 * p->tab.wpb : 0; }
+int wreg_variant(const WregPlan* p) { return p ? (p->da ? 2 : 1) : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)

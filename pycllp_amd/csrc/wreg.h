@@ -30,4 +30,6 @@ hipError_t wreg_launch_newton(WregPlan* p, long B, const double* x, const double
 hipError_t wreg_launch_ldl_solve(int n, long B, const double* A, const double* rhs, double* out, double floor_,
                                  int num_cu, hipStream_t st);
 int wreg_lds_bytes(const WregPlan* p);
+int wreg_block_threads(const WregPlan* p);   // 64 x waves per workgroup
+int wreg_variant(const WregPlan* p);         // 1 = term tables, 2 = dense image
 #endif

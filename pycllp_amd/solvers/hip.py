@@ -495,10 +495,12 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
 
     def launch_info(self):
         """grid / block / LDS bytes of the last solve and which kernel ran it: 'wave' = the register-resident
-        one-LP-per-wavefront kernel (csrc/ipm_wreg.hip), 'block' = the one-LP-per-workgroup kernel (csrc/ipm_block.inc)."""
+        one-LP-per-wavefront kernel (csrc/ipm_wreg.hip; 'variant': on Gram term 'tables' or on a 'dense image' of A), 'block' = the
+        one-LP-per-workgroup kernel (csrc/ipm_block.inc)."""
         vals = [ctypes.c_int() for _ in range(4)]
         _native.check(_native.lib().pycllp_hip_sparse_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
                       "pycllp_hip_sparse_launch_info")
         d = dict(zip(("grid", "block", "lds_bytes", "kernel"), [v.value for v in vals]))
+        d["variant"] = {0: "block", 1: "tables", 2: "dense image"}[d["kernel"]]
         d["kernel"] = "wave" if d["kernel"] else "block"
         return d

@@ -836,7 +836,7 @@ def test_dense_image_variant_of_the_wave_kernel(case):
         s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
         lp.init(s)
         st = lp.solve(s)
-        assert s.launch_info()["kernel"] == "wave"
+        assert s.launch_info()["kernel"] == "wave" and s.launch_info()["variant"] == "dense image"
         r = oracle_on(lp, flags=32 if hsd else 0)
         np.testing.assert_array_equal(st, r["status"])
         assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
