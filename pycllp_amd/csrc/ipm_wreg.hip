@@ -583,24 +583,34 @@ struct WReg {
             ra[J] = ib + 8 * (unsigned)((rok[J] ? r : 0) * AS + q);
         }
         const int ks = (AS - 1) / 4;
+        // operands of k-step s: a[J] = A[16J + c16][4s + q] (0 in the padded rows), dk = d[4s + q]
+        auto load_step = [&](int s, double (&a)[MB], double& dk) {
+            dk = *(const __attribute__((address_space(3))) double*)(size_t)(db + 32 * s);
+#pragma unroll
+            for (int J = 0; J < MB; J++) {
+                const double v = *(const __attribute__((address_space(3))) double*)(size_t)(ra[J] + 32 * s);
+                a[J] = rok[J] ? v : 0.0;
+            }
+        };
         // (at most 14 off-diagonal accumulators per pass over the columns: with all 28 of m = 128 live next to the blocks
-        // already parked the register file overflows)
+        // already parked the register file overflows).  The loop is software-pipelined by hand: the operands of step s + 1
+        // are requested before the MFMAs of step s are issued, so their LDS round trip runs under the matrix pipe's time.
         constexpr int PB = 14, NPASS = (G::NBLK + PB - 1) / PB;
         static_for<0, NPASS>([&](auto Hc) {
             constexpr int b0 = PB * decltype(Hc)::value, b1 = (b0 + PB < G::NBLK) ? b0 + PB : G::NBLK;
             double4_t acc[PB];
 #pragma unroll
             for (int b = 0; b < PB; b++) acc[b] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
+            double a[MB], dk;
+            load_step(0, a, dk);
+            // (four k-steps per trip: the allocator keeps the loop-carried accumulators in VGPRs and copies them to the
+            // accumulator file and back around every trip -- 16 moves per MFMA with one step per trip, 170 instead of 64 cycles)
+#pragma unroll 4
             for (int s = 0; s < ks; s++) {
-                double a[MB], ad[MB];
-                const double dk = *(const __attribute__((address_space(3))) double*)(size_t)(db + 32 * s);
+                double an[MB], dkn, ad[MB];
+                load_step((s + 1 < ks) ? s + 1 : s, an, dkn);
 #pragma unroll
-                for (int J = 0; J < MB; J++) {
-                    const double v = *(const __attribute__((address_space(3))) double*)(size_t)(ra[J] + 32 * s);
-                    a[J] = rok[J] ? v : 0.0;
-                    ad[J] = a[J] * dk;
-                }
+                for (int J = 0; J < MB; J++) ad[J] = a[J] * dk;
                 static_for<0, MB>([&](auto Kc) {
                     constexpr int K = decltype(Kc)::value;
                     static_for<K + 1, MB>([&](auto Ic) {
@@ -610,6 +620,9 @@ struct WReg {
                             acc[bx - b0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[K], a[I], acc[bx - b0], 0, 0, 0);
                     });
                 });
+#pragma unroll
+                for (int J = 0; J < MB; J++) a[J] = an[J];
+                dk = dkn;
             }
 #pragma unroll
             for (int b = b0; b < b1; b++) park(P[b], acc[b - b0]);
@@ -617,14 +630,18 @@ struct WReg {
         double4_t dacc[MB];
 #pragma unroll
         for (int K = 0; K < MB; K++) dacc[K] = (double4_t){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-        for (int s = 0; s < ks; s++) {
-            const double dk = *(const __attribute__((address_space(3))) double*)(size_t)(db + 32 * s);
+        {
+            double a[MB], dk;
+            load_step(0, a, dk);
+#pragma unroll 4
+            for (int s = 0; s < ks; s++) {
+                double an[MB], dkn;
+                load_step((s + 1 < ks) ? s + 1 : s, an, dkn);
 #pragma unroll
-            for (int J = 0; J < MB; J++) {
-                const double v = *(const __attribute__((address_space(3))) double*)(size_t)(ra[J] + 32 * s);
-                const double a = rok[J] ? v : 0.0;
-                dacc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a * dk, a, dacc[J], 0, 0, 0);
+                for (int J = 0; J < MB; J++) dacc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[J] * dk, a[J], dacc[J], 0, 0, 0);
+#pragma unroll
+                for (int J = 0; J < MB; J++) a[J] = an[J];
+                dk = dkn;
             }
         }
         // accumulator register r of lane (q, c16) = element [row 4r + q][column c16] of the block: lower triangle (with the

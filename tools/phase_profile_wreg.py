@@ -11,7 +11,11 @@ names = ["0 A'y, norms, d, t, A x, tests, A(dt), diag(M)", "1 Gram scatter + blo
          "3 LDL': original diagonal block from the tables -> tile", "4 LDL': tile -> rows, 16-step pivot chain", "5 LDL': W = L_KK^-1, panel (MFMA)", "6 LDL': trailing update (MFMA)",
          "7 block substitution (solve)", "8 A'dy, dx, A dx, refinement test", "9 step, load/store LP", "10 (of 0) A'y, sigma, gamma, objectives", "11 (of 0) d, t, A x, rho, stop tests"]
 m, n, B = 128, 256, int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-A, b, c = problems.random_sparse_arrays(m, n, B, density=0.025, seed=0)
+if os.environ.get("DENSE"):      # DENSE=m,n: a dense A of that shape (dense-image variant of the kernel)
+    m, n = (int(v) for v in os.environ["DENSE"].split(","))
+    A, b, c = problems.random_dense_arrays(m, n, B, seed=0)
+else:
+    A, b, c = problems.random_sparse_arrays(m, n, B, density=0.025, seed=0)
 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
 s = solver_registry["hip_sparse_primal_normal"](hsd=bool(int(os.environ.get("HSD", "0")))); lp.init(s)
 L = _native.lib()
@@ -24,7 +28,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); buf = s.solve_device(be, ce); e1.record(); torch.cuda.synchronize()
 p = prof.cpu().numpy().reshape(-1, NPHASE).astype(np.float64); p = p[p.sum(1) > 0]
 iters = buf["iters"].cpu().numpy()
-print("kernel %.1f ms (stamped build), %d waves, mean iterations %.2f" % (e0.elapsed_time(e1), len(p), iters.mean()))
+print("kernel %.1f ms (stamped build), %d waves, mean iterations %.2f, %s" % (e0.elapsed_time(e1), len(p), iters.mean(), s.launch_info()))
 per_it = p.sum(0) / iters.sum()
 for i in range(NPHASE):
     print("%-55s %6.1f%%   %9.0f cycles per LP-iteration" % (names[i], 100 * p[:, i].sum() / p.sum(), per_it[i]))
