@@ -605,8 +605,11 @@ struct WReg {
             load_step(0, a, dk);
             // (four k-steps per trip: the allocator keeps the loop-carried accumulators in VGPRs and copies them to the
             // accumulator file and back around every trip -- 16 moves per MFMA with one step per trip, 170 instead of 64 cycles)
-#pragma unroll 4
-            for (int s = 0; s < ks; s++) {
+#pragma unroll 1
+            for (int s0 = 0; s0 < ks; s0 += 4)         // (the image is padded to a multiple of 16 columns: ks % 4 == 0)
+#pragma unroll
+            for (int su = 0; su < 4; su++) {
+                const int s = s0 + su;
                 double an[MB], dkn, ad[MB];
                 load_step((s + 1 < ks) ? s + 1 : s, an, dkn);
 #pragma unroll
@@ -633,8 +636,11 @@ struct WReg {
         {
             double a[MB], dk;
             load_step(0, a, dk);
-#pragma unroll 4
-            for (int s = 0; s < ks; s++) {
+#pragma unroll 1
+            for (int s0 = 0; s0 < ks; s0 += 4)
+#pragma unroll
+            for (int su = 0; su < 4; su++) {
+                const int s = s0 + su;
                 double an[MB], dkn;
                 load_step((s + 1 < ks) ? s + 1 : s, an, dkn);
 #pragma unroll
@@ -1867,7 +1873,7 @@ static int wreg_plan_create_dense(int m, int n, int nnz, const double* val, cons
         for (int e = ptr[i]; e < ptr[i + 1]; e++)
             if (col[e] >= n - m) { if (col[e] != n - m + i || val[e] != 1.0) sl = false; else tail_cnt[i]++; }
     for (int i = 0; i < m && sl; i++) if (tail_cnt[i] != 1) sl = false;
-    const int nd = sl ? n - m : n, ndp = ((std::max(nd, 1) + 7) / 8) * 8, AS = ndp + 1, R = ((m + 7) / 8) * 8;
+    const int nd = sl ? n - m : n, ndp = ((std::max(nd, 1) + 15) / 16) * 16, AS = ndp + 1, R = ((m + 7) / 8) * 8;   // (16: gram_dense takes four k-steps per trip)
     WregPlan* P = new WregPlan();
     WregTab& T = P->tab;
     memset(&T, 0, sizeof(T));
