@@ -513,7 +513,7 @@ struct WReg {
     // slots of the W area, where factor() picks block K up when its turn comes and then overwrites it with W_K.
     __device__ __forceinline__ void gram(const double (&Md)[MR]) {
         if constexpr (DA) { gram_dense(Md); return; }
-        static_assert((G::NBLK < HB ? G::NBLK : HB) * 256 <= STAGE_D + MB * WL, "staging area too small");
+        static_assert(DA || (G::NBLK < HB ? G::NBLK : HB) * 256 <= STAGE_D + MB * WL, "staging area too small");
         const double2_t zero = {0.0, 0.0};
         // zero the diagonal-block slots, scatter group g's diagonal-block entries (dsts relative to `base`), set the diagonal
         // from Md (row 16K + i lives in lane (16K + i) % 64 of register (16K + i) / 64)
@@ -595,7 +595,7 @@ struct WReg {
         // (at most 14 off-diagonal accumulators per pass over the columns: with all 28 of m = 128 live next to the blocks
         // already parked the register file overflows).  The loop is software-pipelined by hand: the operands of step s + 1
         // are requested before the MFMAs of step s are issued, so their LDS round trip runs under the matrix pipe's time.
-        constexpr int PB = 14, NPASS = (G::NBLK + PB - 1) / PB;
+        constexpr int PB = (G::NBLK <= 16) ? (G::NBLK > 0 ? G::NBLK : 1) : 14, NPASS = (G::NBLK + PB - 1) / PB;
         static_for<0, NPASS>([&](auto Hc) {
             constexpr int b0 = PB * decltype(Hc)::value, b1 = (b0 + PB < G::NBLK) ? b0 + PB : G::NBLK;
             double4_t acc[PB];
@@ -1110,7 +1110,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
         while (running) {
             double x[NQ], z[NQ], cv[NQ], rho[MR];
 #pragma unroll
-            for (int r2 = 0; r2 < MR; r2++) rho[r2] = w.flr_()[lane + 64 * r2];
+            for (int r2 = 0; r2 < MR; r2++) rho[r2] = (lane + 64 * r2 < MP) ? w.flr_()[lane + 64 * r2] : 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
                 x[qq] = w.stage_()[64 * NQ + lane + 64 * qq];
@@ -1135,7 +1135,11 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                 wave_lds_sync();
                 w.template Arow<false>(vx, Ax, dm);
 #pragma unroll
-                for (int r2 = 0; r2 < MR; r2++) { rho[r2] = okr[r2] ? w.bs_()[lane + 64 * r2] - Ax[r2] : 0.0; w.flr_()[lane + 64 * r2] = rho[r2]; }
+                for (int r2 = 0; r2 < MR; r2++) {
+                    const int i = lane + 64 * r2;
+                    rho[r2] = okr[r2] ? w.bs_()[i] - Ax[r2] : 0.0;
+                    if (i < MP) w.flr_()[i] = rho[r2];
+                }
                 wave_lds_sync();
                 refresh = false; fresh = true;
             }
@@ -1210,7 +1214,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                     double dy[MR], wv[NQ], dx[NQ], e[MR], rhn[MR];
                     bool bad;
 #pragma unroll
-                    for (int r2 = 0; r2 < MR; r2++) rhn[r2] = w.flr_()[lane + 64 * r2];
+                    for (int r2 = 0; r2 < MR; r2++) rhn[r2] = (lane + 64 * r2 < MP) ? w.flr_()[lane + 64 * r2] : 0.0;
                     (void)newton_solve<true>(w, okc, okr, rhn, etol, o.max_refine, mu, dy, dx, wv, e, bad STAMP_PASS);
 #pragma unroll
                     for (int qq = 0; qq < NQ; qq++) {
@@ -1234,8 +1238,10 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
                         for (int r2 = 0; r2 < MR; r2++) {
                             const int i = lane + 64 * r2;
-                            if (i < MP) w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
-                            w.flr_()[i] = fma(-theta, rhn[r2] - e[r2], rhn[r2]);       // A dx = rho - e
+                            if (i < MP) {
+                                w.ys_()[i] = fma(theta, dy[r2], w.ys_()[i]);
+                                w.flr_()[i] = fma(-theta, rhn[r2] - e[r2], rhn[r2]);       // A dx = rho - e
+                            }
                         }
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) {
@@ -1850,8 +1856,9 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false),
-                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
+const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(6, 6, false),
+                                WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false),
+                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(6, 4, true), WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace

@@ -798,10 +798,12 @@ def test_sparse_wave_and_block_kernels_agree():
         assert rel_err(w.primal_obj, k.primal_obj).max() < 1e-9 and rel_err(w.dual_obj, k.dual_obj).max() < 1e-9
 
 
-@pytest.mark.parametrize("m,n,variant", [(48, 200, "n <= 256"), (100, 280, "n <= 384"), (60, 440, "n <= 512")])
+@pytest.mark.parametrize("m,n,variant", [(48, 200, "n <= 256"), (100, 280, "n <= 384"), (60, 440, "n <= 512"),
+                                         (80, 200, "m <= 96 (rows beyond the 96 LDS m-vector entries of that variant)")])
 def test_sparse_wave_kernel_column_variants(m, n, variant):
     """The register-resident kernel is compiled for 4, 6 and 8 N-vector registers per lane (N <= 256, 384, 512 columns of the
-    equality form): one shape per variant, on the wave kernel, against the oracle LP by LP."""
+    equality form) and for 4, 6 and 8 block rows (m <= 64, 96, 128): one shape per variant, on the wave kernel, against the
+    oracle LP by LP."""
     A, b, c = problems.random_sparse_arrays(m, n, 24, density=0.02, seed=5)
     lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
     assert lp.ncols == m + n
@@ -816,14 +818,14 @@ def test_sparse_wave_kernel_column_variants(m, n, variant):
         assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
 
 
-@pytest.mark.parametrize("case", ["standard 64x64", "standard 100x80", "equality 40x100 without identity columns"])
+@pytest.mark.parametrize("case", ["standard 64x64", "standard 90x80", "standard 100x80", "equality 40x100 without identity columns"])
 def test_dense_image_variant_of_the_wave_kernel(case):
     """A matrix whose Gram term list does not fit into LDS but whose dense image does runs on the dense-image variant of the
     register-resident kernel (MFMA Gram straight from the image, image mat-vecs): dense StandardLPs -- the identity columns of
     the equality form stay out of the image -- and a dense EqualityLP that has none.  Against the oracle LP by LP."""
     rs = np.random.RandomState(8)
     if case.startswith("standard"):
-        m, n = (64, 64) if "64x64" in case else (100, 80)
+        m, n = {"64x64": (64, 64), "90x80": (90, 80), "100x80": (100, 80)}[case.split()[1]]
         A, b, c = problems.random_dense_arrays(m, n, 48, seed=m)
         lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
     else:

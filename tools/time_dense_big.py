@@ -6,7 +6,7 @@ import numpy as np, torch
 from pycllp_amd import problems
 from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry
-for m, n, B in ((100, 80, 4096), (64, 64, 8192), (48, 100, 8192)):
+for m, n, B in ((100, 80, 4096), (90, 80, 4096), (64, 64, 8192), (48, 100, 8192)):
     A, b, c = problems.random_dense_arrays(m, n, B, seed=0)
     lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
     s = solver_registry["hip_dense_primal_normal"](hsd=False); lp.init(s)
