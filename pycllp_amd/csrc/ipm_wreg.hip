@@ -1856,9 +1856,10 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(6, 6, false),
+const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(6, 6, false), WVARIANT(7, 6, false),
                                 WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false),
-                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(6, 4, true), WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
+                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(6, 4, true), WVARIANT(7, 4, true),
+                                WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
 const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
 
 }  // namespace
