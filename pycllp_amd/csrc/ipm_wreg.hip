@@ -31,11 +31,14 @@
 //     three pinned values where it is used (WReg::pin): no scratch traffic inside the iteration loop;
 //   * the triangular solves are 16-row block steps: 4 FMAs per off-diagonal block, quad/row reductions by
 //     v_permlane swaps and DPP.
-// Variants (MB 16-row blocks, NQ 64-column N-vector registers): (4,2) (4,4) (8,4) (8,6) (8,8); see kWVariants.
+// Variants (MB 16-row blocks, NQ 64-column N-vector registers; term tables or dense image): see kWVariantsTab / kWVariantsDA.
 // The Nocedal-Wright guard (ldl.cl:487) is not applied here: the sweep records whether it WOULD have bitten and such an
 // LP (never seen on a positive definite M) is deferred to ipm_block_kernel, which applies it exactly.
 // Semantics = oracle/ipm_dense_ref.c (ipm_one_path / hsd_one_raw), like every other kernel of this library.
 // tools/wreg_sim.py is a lane-level numpy model of the layouts used below.
+#ifndef WREG_PART
+#define WREG_PART 0     // 0: table variants + host code; 1: the dense-image variants only (second translation unit)
+#endif
 #include "wreg.h"
 
 namespace {
@@ -72,9 +75,6 @@ __host__ __device__ constexpr int stage_d(int NQ) { return tile_off(NQ) + TILE_D
 constexpr int HB = 8;            // 16 x 16 blocks per Gram staging chunk: the stage and, behind it, the still unused W area (16 KB)
 constexpr int WL = 144;          // doubles per diagonal-block slot: first the ORIGINAL diagonal block of M (lower triangle with
                                  // diagonal, row i at i(i+1)/2: 136), from stage K on W_K (strictly lower triangle, row i at i(i-1)/2)
-constexpr int MAX_NQ = 8;
-constexpr int META_COFF = MAX_NQ, META_SEG = 2 * MAX_NQ, META_N = META_SEG + 16;
-
 template <int MB>
 struct WGeo {
     static constexpr int MP = 16 * MB;
@@ -88,33 +88,6 @@ struct WGeo {
     // the diagonal blocks' entries ride with the last chunk when its blocks end in front of the W area (where they go)
     __host__ __device__ static constexpr bool MERGE_DIAG(int NQ) { return NBLK > 0 && (NBLK - HB * (NCHUNK - 1)) * 256 <= stage_d(NQ); }
     static constexpr int WAVE_D(int NQ) { return stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL; }   // per-wave LDS doubles
-};
-
-// Device view of the tables of one constraint matrix (built by wreg_plan_create).
-struct WregTab {
-    int m, n, nnz;
-    int rmax, n_lev, n_term;
-    int meta[META_N];     // [0..8) ELL depth of column register q, [META_COFF..) its first ELL slot, [META_SEG..) first level
-                          // (index into lev) of Gram group g: the NCHUNK staging chunks of off-diagonal blocks, then the
-                          // diagonal blocks; NCHUNK + 2 used -- copied to LDS
-    const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
-    // A by columns in ELL form over column POSITIONS: the columns are dealt to the (lane, register) positions of the
-    // N-vectors sorted by length, so that each register's 64 columns are about equally long (JDS); colmap[pos] = 8 x column
-    const double* ec_val; const unsigned short* ec_row; const unsigned* colmap; int ctot;   // (a byte offset; PAD_OFF for pos >= n)
-    // Gram terms a_ij a_kj d_j of the strictly lower triangle of M, one record per term: weight a_ij a_kj, column position
-    // of j, destination offset inside the group's staging area.  Inside a group the terms are ordered by LEVEL = rank of
-    // the term inside its entry (i, k): level 0 holds the first term of every entry, level 1 the second term of the
-    // entries that have one, ...; lev[] holds the item boundaries, level l of the table = items [lev[l], lev[l + 1]).
-    // Destinations are distinct inside a level, so a level is one flat pass with no inner loop; level 0 stores, the
-    // later levels accumulate in the same order a per-entry loop would.
-    const double* t_w; const unsigned* t_cd; const int* lev;     // t_cd = column position | destination << 16
-    int o_csr_val, o_ec_val, o_t_w, o_wave, o_lev, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
-        o_t_cd;                                           // LDS byte offsets
-    int wave_doubles, lds_bytes;
-    // dense variant (DA): no tables, A as a row-major image [img_rows][as] of its first nd columns (the remaining n - nd
-    // columns are the identity, column nd + i = e_i, or there are none), as = nd rounded up to 8, + 1
-    int nd, as, img_rows, o_img, wpb;
-    const double* img;
 };
 
 // ---- cross-lane helpers ----------------------------------------------------------------------------------------
@@ -1801,6 +1774,9 @@ __global__ void wreg_selftest_kernel(double* out) {
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef WREG_PART
+#error "WREG_PART must be defined before this point"
+#endif
 struct WregPlan {
     WregTab tab;
     int mb, nq;
@@ -1817,11 +1793,6 @@ size_t put(std::vector<char>& host, const std::vector<T>& v) {
     if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
     return off;
 }
-
-typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const double*, double*, double*, double*, double*,
-                                double*, int*, int*, int*, int*, DevOpts, int, hipStream_t);
-typedef hipError_t (*wnewton_fn)(const WregTab&, long, const double*, const double*, const double*, const double*,
-                                 const double*, double, double*, int*, int*, DevOpts, int, hipStream_t);
 
 template <int MB, int NQ, bool DA>
 hipError_t do_solve(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
@@ -1853,16 +1824,33 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
     return hipGetLastError();
 }
 
-struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
-const WVariant kWVariants[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(6, 6, false), WVARIANT(7, 6, false),
-                                WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false),
-                                WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(6, 4, true), WVARIANT(7, 4, true),
-                                WVARIANT(8, 4, true), WVARIANT(8, 6, true) };
-const int kNumWVariants = sizeof(kWVariants) / sizeof(kWVariants[0]);
+#if WREG_PART == 0
+const WVariant kWVariantsTab[] = { WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(6, 6, false), WVARIANT(7, 6, false),
+                                   WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false) };
+const int kNumWVariantsTab = sizeof(kWVariantsTab) / sizeof(kWVariantsTab[0]);
+const int kNumWVariants = kNumWVariantsTab + kNumWVariantsDA;
+struct VariantList { const WVariant& operator[](int i) const { return i < kNumWVariantsTab ? kWVariantsTab[i] : kWVariantsDA[i - kNumWVariantsTab]; } };
+const VariantList kWVariants{};
+#endif
 
 }  // namespace
+
+#if WREG_PART == 1
+#define WVARIANTS_DA { WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(6, 4, true), WVARIANT(7, 4, true), \
+                       WVARIANT(8, 4, true), WVARIANT(8, 6, true) }
+#ifdef __HIP_DEVICE_COMPILE__
+// device pass: a file-local copy of the table -- it is never emitted, but referencing the launchers is what makes the kernels
+// they launch get instantiated (an external table of host function pointers would be emitted into the device object and
+// fail to link there)
+namespace { [[maybe_unused]] const WVariant kWVariantsDA_instantiate[] = WVARIANTS_DA; }
+#else
+extern const WVariant kWVariantsDA[] = WVARIANTS_DA;
+extern const int kNumWVariantsDA = sizeof(kWVariantsDA) / sizeof(kWVariantsDA[0]);
+#endif
+#endif
+#if WREG_PART == 0
 
 // Plan with A as a dense image in LDS (no tables): for matrices whose Gram term list does not fit -- dense A's, e.g. the LPs
 // hip_dense_primal_normal hands over beyond m = 32.  The last m columns are kept out of the image when they are the
@@ -2153,3 +2141,4 @@ extern "C" int pycllp_hip_debug_wreg_selftest(double* out_dev, void* stream) {
     hipLaunchKernelGGL(wreg_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out_dev);
     return (int)hipGetLastError();
 }
+#endif  // WREG_PART == 0

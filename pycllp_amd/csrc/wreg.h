@@ -4,6 +4,49 @@
 #define PYCLLP_WREG_H
 #include "wave_common.h"
 
+// ---- shared between the translation units the wave kernels are compiled in (ipm_wreg.hip, twice: WREG_PART 0 / 1) ----
+constexpr int MAX_NQ = 8;
+constexpr int META_COFF = MAX_NQ, META_SEG = 2 * MAX_NQ, META_N = META_SEG + 16;
+
+
+// Device view of the tables of one constraint matrix (built by wreg_plan_create).
+struct WregTab {
+    int m, n, nnz;
+    int rmax, n_lev, n_term;
+    int meta[META_N];     // [0..8) ELL depth of column register q, [META_COFF..) its first ELL slot, [META_SEG..) first level
+                          // (index into lev) of Gram group g: the NCHUNK staging chunks of off-diagonal blocks, then the
+                          // diagonal blocks; NCHUNK + 2 used -- copied to LDS
+    const double* csr_val; const unsigned short* csr_col; const unsigned short* csr_ptr; const unsigned short* csr_len;
+    // A by columns in ELL form over column POSITIONS: the columns are dealt to the (lane, register) positions of the
+    // N-vectors sorted by length, so that each register's 64 columns are about equally long (JDS); colmap[pos] = 8 x column
+    const double* ec_val; const unsigned short* ec_row; const unsigned* colmap; int ctot;   // (a byte offset; PAD_OFF for pos >= n)
+    // Gram terms a_ij a_kj d_j of the strictly lower triangle of M, one record per term: weight a_ij a_kj, column position
+    // of j, destination offset inside the group's staging area.  Inside a group the terms are ordered by LEVEL = rank of
+    // the term inside its entry (i, k): level 0 holds the first term of every entry, level 1 the second term of the
+    // entries that have one, ...; lev[] holds the item boundaries, level l of the table = items [lev[l], lev[l + 1]).
+    // Destinations are distinct inside a level, so a level is one flat pass with no inner loop; level 0 stores, the
+    // later levels accumulate in the same order a per-entry loop would.
+    const double* t_w; const unsigned* t_cd; const int* lev;     // t_cd = column position | destination << 16
+    int o_csr_val, o_ec_val, o_t_w, o_wave, o_lev, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
+        o_t_cd;                                           // LDS byte offsets
+    int wave_doubles, lds_bytes;
+    // dense variant (DA): no tables, A as a row-major image [img_rows][as] of its first nd columns (the remaining n - nd
+    // columns are the identity, column nd + i = e_i, or there are none), as = nd rounded up to 8, + 1
+    int nd, as, img_rows, o_img, wpb;
+    const double* img;
+};
+
+
+typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const double*, double*, double*, double*, double*,
+                                double*, int*, int*, int*, int*, DevOpts, int, hipStream_t);
+typedef hipError_t (*wnewton_fn)(const WregTab&, long, const double*, const double*, const double*, const double*,
+                                 const double*, double, double*, int*, int*, DevOpts, int, hipStream_t);
+
+struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
+// the dense-image variants live in the second translation unit (same source, -DWREG_PART=1), compiled in parallel
+extern const WVariant kWVariantsDA[];
+extern const int kNumWVariantsDA;
+
 struct WregPlan;   // host tables + device copies for one shared constraint matrix
 
 // Builds the plan from a host CSR copy of A (m rows, n columns, equality form).  Returns 0 and *out on success,

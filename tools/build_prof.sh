@@ -3,8 +3,10 @@
 set -e
 cd /root/repo
 mkdir -p proflib
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DPYCLLP_PROFILE -c -o /tmp/wreg_prof.o pycllp_amd/csrc/ipm_wreg.hip &
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DPYCLLP_PROFILE $PROF_EXTRA -c -o /tmp/dense_prof.o pycllp_amd/csrc/ipm_dense.hip &
+F="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -DPYCLLP_PROFILE"
+/opt/rocm/bin/hipcc $F -DWREG_PART=0 -c -o /tmp/wreg_prof.o pycllp_amd/csrc/ipm_wreg.hip &
+/opt/rocm/bin/hipcc $F -DWREG_PART=1 -c -o /tmp/wreg_da_prof.o pycllp_amd/csrc/ipm_wreg.hip &
+/opt/rocm/bin/hipcc $F $PROF_EXTRA -c -o /tmp/dense_prof.o pycllp_amd/csrc/ipm_dense.hip &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o proflib/libpycllp_hip_prof.so /tmp/dense_prof.o /tmp/wreg_prof.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o proflib/libpycllp_hip_prof.so /tmp/dense_prof.o /tmp/wreg_prof.o /tmp/wreg_da_prof.o
 ls -la proflib/
