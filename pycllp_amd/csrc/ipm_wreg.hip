@@ -1827,7 +1827,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
-const WVariant kWVariantsTab[] = { WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
+const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
                                    WVARIANT(7, 6, false), WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false) };
 const int kNumWVariantsTab = sizeof(kWVariantsTab) / sizeof(kWVariantsTab[0]);
 const int kNumWVariants = kNumWVariantsTab + kNumWVariantsDA;
@@ -1838,7 +1838,7 @@ const VariantList kWVariants{};
 }  // namespace
 
 #if WREG_PART == 1
-#define WVARIANTS_DA { WVARIANT(3, 4, true), WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(5, 4, true), WVARIANT(6, 4, true), \
+#define WVARIANTS_DA { WVARIANT(1, 4, true), WVARIANT(2, 4, true), WVARIANT(3, 4, true), WVARIANT(4, 2, true), WVARIANT(4, 4, true), WVARIANT(5, 4, true), WVARIANT(6, 4, true), \
                        WVARIANT(7, 4, true), WVARIANT(8, 4, true), WVARIANT(8, 6, true) }
 #ifdef __HIP_DEVICE_COMPILE__
 // device pass: a file-local copy of the table -- it is never emitted, but referencing the launchers is what makes the kernels

@@ -799,7 +799,8 @@ def test_sparse_wave_and_block_kernels_agree():
 
 
 @pytest.mark.parametrize("m,n,variant", [(48, 200, "n <= 256"), (100, 280, "n <= 384"), (60, 440, "n <= 512"),
-                                         (80, 200, "m <= 80 / 96 (rows beyond the LDS m-vector entries of those variants)"), (40, 120, "m <= 48"), (90, 300, "m <= 96")])
+                                         (80, 200, "m <= 80 / 96 (rows beyond the LDS m-vector entries of those variants)"), (40, 120, "m <= 48"), (90, 300, "m <= 96"),
+                                         (10, 200, "m <= 16"), (30, 200, "m <= 32")])
 def test_sparse_wave_kernel_column_variants(m, n, variant):
     """The register-resident kernel is compiled for 4, 6 and 8 N-vector registers per lane (N <= 256, 384, 512 columns of the
     equality form) and for 4, 6 and 8 block rows (m <= 64, 96, 128): one shape per variant, on the wave kernel, against the
