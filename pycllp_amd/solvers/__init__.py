@@ -10,33 +10,45 @@ real ``pycllp`` is importable, :func:`register_with_pycllp` also inserts the HIP
 solver_registry = {}
 
 
+def _announce(cls):
+    """A solver class with a ``name`` is reachable as ``solver_registry[name]`` from the moment it exists."""
+    key = getattr(cls, "name", None)
+    if key is not None:
+        solver_registry[key] = cls
+    return cls
+
+
 class MetaSolver(type):
-    def __new__(mcs, clsname, bases, attrs):
-        newclass = super(MetaSolver, mcs).__new__(mcs, clsname, bases, attrs)
-        if newclass.name is not None:
-            solver_registry[newclass.name] = newclass
-        return newclass
+    """The reference's metaclass name (``pycllp/solvers/__init__.py:6-11``); here the registration is done once the class
+    object is complete (``__init__``), through :func:`_announce`."""
+
+    def __init__(cls, clsname, bases, namespace):
+        type.__init__(cls, clsname, bases, namespace)
+        _announce(cls)
 
 
-class BaseSolver(MetaSolver("_BaseSolver", (object,), {"name": None})):
+class BaseSolver(metaclass=MetaSolver):
+    """Plugin contract (``pycllp/solvers/__init__.py:14-21``): ``init(lp)`` once per constraint matrix, ``solve(lp)`` per batch."""
     name = None
 
     def init(self, lp, verbose=0):
-        raise NotImplementedError()
+        raise NotImplementedError("%s does not implement init()" % type(self).__name__)
 
     def solve(self, lp, verbose=0):
-        raise NotImplementedError()
+        raise NotImplementedError("%s does not implement solve()" % type(self).__name__)
 
 
 class BaseCSCSolver(BaseSolver):
-    """Mirror of ``pycllp/solvers/__init__.py:24-26``: ``init`` caches the compressed-sparse-column arrays of ``lp.A``."""
+    """Mirror of ``pycllp/solvers/__init__.py:24-26``: ``init`` caches the compressed-sparse-column arrays of ``lp.A``
+    as ``self.A`` (values), ``self.Ai`` (row indices), ``self.Ak`` (column starts)."""
 
     def init(self, lp, verbose=0):
-        self.A, self.Ai, self.Ak = lp.A.tocsc_arrays()
+        values, rows, starts = lp.A.tocsc_arrays()
+        self.A, self.Ai, self.Ak = values, rows, starts
 
 
 class BaseGeneralSolver(BaseSolver):
-    pass
+    """Marker base of solvers that take a ``GeneralLP`` (``pycllp/solvers/__init__.py:29-30``)."""
 
 
 def register_with_pycllp():
