@@ -3,7 +3,7 @@ stand-alone register LDL' solve, the stand-alone sparse Newton step and the full
 import ctypes, sys, os, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pycllp_amd import _native, problems
 from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry

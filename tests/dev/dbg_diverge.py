@@ -1,7 +1,7 @@
 """Where do kernel and oracle part ways on the two diverging 1x2 LPs of test_infeasible_and_unbounded_status_codes_match_oracle?
 Runs both with max_iter = k for growing k and prints the first k at which x, y or z differ by more than 1e-9 relative."""
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pycllp_amd.lp import SparseMatrix, EqualityLP
 from pycllp_amd.solvers import solver_registry
 from oracle import port

@@ -1,5 +1,5 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pycllp_amd import problems
 from pycllp_amd.lp import SparseMatrix, StandardLP
 from pycllp_amd.solvers import solver_registry

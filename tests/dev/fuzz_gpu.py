@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HIP solvers against the oracle (development aid, run on the GPU box)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pycllp_amd import problems
 from pycllp_amd.lp import SparseMatrix, StandardLP, EqualityLP

@@ -322,7 +322,7 @@ def test_infeasible_and_unbounded_lps_reference_path_and_default():
     """Two 1 x 2 LPs, one infeasible, one unbounded.
     (a) hsd=False, the reference's path (10x-growth heuristic, primal_normal.cl:261-269): kernel and oracle walk the SAME
     trajectory -- x, y, z after k iterations agree to 1e-12 relative for every k (measured 5e-15 over 59 iterations,
-    tools/dbg_diverge.py) -- and give the same verdict.  The iteration AT WHICH the heuristic fires is not comparable:
+    tests/dev/dbg_diverge.py) -- and give the same verdict.  The iteration AT WHICH the heuristic fires is not comparable:
     it is tripped by a 10x bump of |sigma| = |c - A'y + z|, which on these diverging iterates (|y|, |z| ~ 1e7..1e8, x -> 0)
     is pure cancellation noise of size eps |y|; the kernel carries A'y incrementally, the oracle recomputes it, so the two
     noises differ and the exits fall 10-40 iterations apart (kernel 96 vs oracle 136 here).

@@ -198,7 +198,7 @@ def test_per_problem_values_of_A_in_the_containers():
 
 def test_sparse_generator_terminates_on_narrow_matrices():
     """The >= 3 non-zeros per row rule of the config-5 generator is capped by the number of columns (n = 2 used to loop
-    forever: found by tools/fuzz_gpu.py)."""
+    forever: found by tests/dev/fuzz_gpu.py)."""
     from pycllp_amd import problems
     A, b, c = problems.random_sparse_arrays(7, 2, 3, density=1.0, seed=1)
     assert A.shape == (7, 2) and (np.diff(A.indptr) == 2).all() and b.shape == (3, 7) and c.shape == (3, 2)
