@@ -202,6 +202,76 @@ __device__ __forceinline__ void subst15_down(double& s, const double* l) {      
                  "s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%15 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
                  : "+v"(s) : "v"(l[15]), "v"(l[14]), "v"(l[13]), "v"(l[12]), "v"(l[11]), "v"(l[10]), "v"(l[9]), "v"(l[8]), "v"(l[7]), "v"(l[6]), "v"(l[5]), "v"(l[4]), "v"(l[3]), "v"(l[2]), "v"(l[1]));
 }
+// the same for two right-hand sides at once, the two dependency chains interleaved (each step of one chain stands between two
+// steps of the other: one s_nop 0 more completes the two wait states of the VALU-write -> DPP-read hazard)
+__device__ __forceinline__ void subst15_up2(double& s, double& t, const double* l) {
+    asm volatile("s_nop 1\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%10 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%11 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%13 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%14 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%15 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(s), "+v"(t) : "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3]), "v"(l[4]), "v"(l[5]), "v"(l[6]), "v"(l[7]), "v"(l[8]), "v"(l[9]), "v"(l[10]), "v"(l[11]), "v"(l[12]), "v"(l[13]), "v"(l[14]));
+}
+__device__ __forceinline__ void subst15_down2(double& s, double& t, const double* l) {      // uses l[15] .. l[1]
+    asm volatile("s_nop 1\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%2 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%2 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%3 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%3 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%4 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%4 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%5 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%6 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%6 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%7 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%7 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%11 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%13 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%14 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%15 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\tv_fmac_f64_dpp %0, %0, -%16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, -%16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(s), "+v"(t) : "v"(l[15]), "v"(l[14]), "v"(l[13]), "v"(l[12]), "v"(l[11]), "v"(l[10]), "v"(l[9]), "v"(l[8]), "v"(l[7]), "v"(l[6]), "v"(l[5]), "v"(l[4]), "v"(l[3]), "v"(l[2]), "v"(l[1]));
+}
 // sum_k l[k] * (src of lane k), k = 0 .. 15, accumulated in that order (as the scalar loop it replaces): sixteen fused FMAs
 __device__ __forceinline__ double dot16_bcast(double src, const double* l) {
     double a = 0.0;
