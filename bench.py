@@ -154,6 +154,8 @@ def main():
     multi = world > 1 or args.force_collectives
     reserve = args.reserve_cus if args.reserve_cus is not None else (8 if multi else 0)
     if multi:
+        # (a bare `python bench.py --force-collectives` has no launcher that sets the rendezvous)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         if args.rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
