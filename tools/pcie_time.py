@@ -31,3 +31,17 @@ print("download x,y,z,obj,status,iters   : %.1f ms" % tm(lambda: [st[k].copy_(bu
 for nc in (1, 2, 4, 8, 16):
     s.PIPELINE_CHUNKS = nc
     print("pipeline with %2d chunks           : %.1f ms" % (nc, tm(lambda: lp.solve(s))))
+
+# the sparse shared-A workload (configs[4]'s per-GPU share) through the same host-to-host path
+from pycllp_amd.lp import StandardLP
+B5 = 16384
+A5, b5, c5 = problems.random_sparse_arrays(128, 256, B5, density=0.025, seed=0)
+lp5 = StandardLP(SparseMatrix(matrix=A5), b5, c5, 0.0).to_equality_form()
+s5 = solver_registry["hip_sparse_primal_normal"](hsd=False)
+lp5.init(s5); lp5.solve(s5)
+ts = []
+for _ in range(6):
+    t = time.perf_counter(); lp5.solve(s5); ts.append(time.perf_counter() - t)
+print("sparse5 per call [ms]:", " ".join("%.1f" % (1e3 * t) for t in ts))
+print("sparse5 lp.solve() host-to-host: median %.1f ms -> %.1f k LPs/s (%d LPs of 128 x 256, device-resident: 46.3 ms)"
+      % (1e3 * np.median(ts), B5 / np.median(ts) / 1e3, B5))
