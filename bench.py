@@ -14,6 +14,14 @@ Rank 0 prints ONE JSON line.  `roofline` prices the solve kernel against the FP6
 compute bound: ~1500 flop per compulsory HBM byte, SURVEY section 8d) and also reports the algorithmic HBM rate;
 `cpu_baseline` is the reference's own CPU solver (pycllp/ipo.py -> ipo/hsd.c, built from the reference sources
 into oracle/_ref) timed on one host core on a bounded sample of the same workload.
+
+With one GPU and the default workload the line also carries `secondary`: the other single-GPU configurations of this
+path (configs[1] 4 096 x (16, 32); configs[4]'s per-GPU share on the reference's algorithm and on the homogeneous
+self-dual variant; per-problem values of A on that structure; a dense LP beyond the lane-group kernels, m = 100) --
+each measured the same way (resident inputs, HIP events around the launches, barrier-free wall clock with a device
+synchronise either side), each with its own roofline figures, its parity against the committed golden vectors of the
+reference solver and the reference solver's own time on a bounded sample of THAT workload.  They are records, not the
+headline: `value` is always the configs[2] figure.
 """
 import argparse
 import json
@@ -29,6 +37,7 @@ sys.path.insert(0, ROOT)
 M, N_STD, B_PER_GPU = 32, 64, 65536
 PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (datasheet)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (MI355X_MICROARCH.md)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def flops_per_lp(m, N, iters, refine=0.0):
@@ -36,35 +45,14 @@ def flops_per_lp(m, N, iters, refine=0.0):
     return iters * (m * (m + 1) * N + 8 * m * N + m ** 3 / 3.0 + 4 * m * m * (1 + refine) + 14 * N + 3 * m)
 
 
+def flops_per_lp_sparse(m, N, iters, n_terms, nnz_e):
+    """Term-list Gram assembly and CSR/CSC products instead of the dense m(m+1)N + 8mN; dense m^3/3 LDL'."""
+    return iters * (2 * n_terms + 8 * nnz_e + m ** 3 / 3.0 + 4 * m * m + 14 * N + 3 * m)
+
+
 def bytes_per_lp(m, N):
     """Compulsory HBM traffic of the fused solve: b, c in; x, y, z out; objectives, status, iters."""
     return 8 * (m + N) + 8 * (N + m) + 8 * N + 16 + 8
-
-
-def cpu_baseline(seconds=12.0):
-    """Reference CPU solver (oracle/_ref: ipo.py's hsd.c) on the first LPs of the same batch, 1 core."""
-    from oracle import hsd_ref
-    from pycllp_amd import problems
-    if not hsd_ref.available():
-        from oracle import port
-        A, b, c = problems.random_dense_arrays(M, N_STD, 2048, seed=0)
-        Ae, be, ce = problems.equality_arrays(A, b, c)
-        t = time.perf_counter(); port.dense_solve(Ae, be, ce, nthreads=1); dt = time.perf_counter() - t
-        return {"value": 2048 / dt, "unit": "LPs/s", "cores": 1, "kind": "port",
-                "sample": "first 2048 LPs of the workload, oracle/ipm_dense_ref.c single thread"}
-    nmax = 16384
-    A, b, c = problems.random_dense_arrays(M, N_STD, nmax, seed=0)
-    hsd_ref.solve_standard(A, b[:8], c[:8])   # warm the library
-    done, t0 = 0, time.perf_counter()
-    chunk = 256
-    while done < nmax and time.perf_counter() - t0 < seconds:
-        r = hsd_ref.solve_standard(A, b[done:done + chunk], c[done:done + chunk])
-        assert (r["status"] == 0).all()
-        done += chunk
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "LPs/s", "cores": 1, "kind": "reference",
-            "sample": "first %d LPs of the workload through oracle/_ref (reference ipo/hsd.c), %.1f s, single thread "
-                      "(the C solver keeps global state: not thread-safe)" % (done, dt)}
 
 
 def usable_cores():
@@ -78,6 +66,46 @@ def usable_cores():
     except Exception:
         pass
     return n
+
+
+# ---- CPU legs (rank 0, one GPU only): the reference's own solver on a bounded sample of each workload -------------------
+def cpu_reference(matrices, b, c, seconds, what, chunk=64):
+    """Reference CPU solver (oracle/_ref: pycllp/ipo.py -> ipo/hsd.c) on the first LPs of (b, c), one core, for about
+    `seconds`.  `matrices`: one shared matrix (dense array: every entry handed over, as a dense reference LP does; scipy
+    sparse: structural non-zeros only, as the reference's tocsc_arrays does, lp.py:289-299), or a callable k -> the matrix
+    of LP k (per-problem values: one solver call per LP, the only way the reference can run such a batch)."""
+    from oracle import hsd_ref
+    if not hsd_ref.available():
+        return None
+    per_lp = callable(matrices)
+    get = matrices if per_lp else (lambda k: matrices)
+    hsd_ref.solve_standard(get(0), b[:1], c[:1])     # warm the library
+    done, t0 = 0, time.perf_counter()
+    step = 1 if per_lp else chunk
+    while done < b.shape[0] and time.perf_counter() - t0 < seconds:
+        r = hsd_ref.solve_standard(get(done), b[done:done + step], c[done:done + step])
+        assert (r["status"] == 0).all()
+        done += step
+    done = min(done, b.shape[0])
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "LPs/s", "cores": 1, "kind": "reference",
+            "sample": "first %d LPs of %s through oracle/_ref (reference ipo/hsd.c), %.1f s, single thread "
+                      "(the C solver keeps global state: not thread-safe)" % (done, what, dt)}
+
+
+def cpu_baseline(seconds=10.0):
+    """The headline workload's CPU leg."""
+    from oracle import hsd_ref
+    from pycllp_amd import problems
+    if not hsd_ref.available():
+        from oracle import port
+        A, b, c = problems.random_dense_arrays(M, N_STD, 2048, seed=0)
+        Ae, be, ce = problems.equality_arrays(A, b, c)
+        t = time.perf_counter(); port.dense_solve(Ae, be, ce, nthreads=1); dt = time.perf_counter() - t
+        return {"value": 2048 / dt, "unit": "LPs/s", "cores": 1, "kind": "port",
+                "sample": "first 2048 LPs of the workload, oracle/ipm_dense_ref.c single thread"}
+    A, b, c = problems.random_dense_arrays(M, N_STD, 16384, seed=0)
+    return cpu_reference(A, b, c, seconds, "the workload", chunk=256)
 
 
 def cpu_port(ref_rate=None, nlp_single=1024, nlp_all=16384):
@@ -101,6 +129,207 @@ def cpu_port(ref_rate=None, nlp_single=1024, nlp_all=16384):
                       "%d threads = the CPU share of this box (%.1f s)" % (nlp_single, d1, nlp_all, cores, dt)}
 
 
+# ---- workloads ----------------------------------------------------------------------------------------------------------
+class Workload(object):
+    """One synthetic batch resident on the device + the solver that runs it.  Everything the JSON record of a workload
+    needs is derived here, so that the headline and the secondary records are built by the same code."""
+
+    def __init__(self, name, B, rank, dev, reserve=0, hsd=False):
+        import torch
+        from pycllp_amd import problems
+        from pycllp_amd.lp import SparseMatrix, EqualityLP, StandardLP
+        from pycllp_amd.solvers import solver_registry
+        self.name, self.B, self.hsd, self.dev = name, B, bool(hsd), dev
+        self.per_a = name == "perA"
+        self.sparse = name in ("sparse5", "perA")
+        self.a_values = None
+        if self.sparse:
+            m_, n_ = 128, 256
+            A, b, c = problems.random_sparse_arrays(m_, n_, B, density=0.025, seed=0)
+            if rank:
+                rs = np.random.RandomState(1000003 * rank)
+                b = 0.5 + rs.rand(B, m_); c = 0.5 + rs.rand(B, n_)
+            be, ce = b, np.hstack([c, np.zeros((B, m_))])
+            if self.per_a:
+                # the structure of configs[4]'s A, values of LP k = the shared ones x U[0.75, 1.25) per entry (seed 7 + rank)
+                rows, cols, data = problems.per_problem_values(A, B, seed=7 + rank)
+                self.coo = (rows, cols, data)
+                lp = StandardLP(SparseMatrix(rows, cols, data), b, c, 0.0).to_equality_form()
+            else:
+                lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
+            # hsd=False: the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto'
+            # runs first; hsd=True: the homogeneous self-dual variant (41 instead of 52 iterations, two solves per iteration)
+            solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=self.hsd, reserve_cus=reserve)
+            self.what = ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 non-zeros) "
+                         "-> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)%s"
+                         % (B, m_, n_, n_ + m_, "; PER-PROBLEM VALUES of A on that structure (SURVEY 8f-4; shared x U[0.75,1.25))"
+                            if self.per_a else ""))
+        else:
+            m_, n_ = {"dense3": (M, N_STD), "dense2": (16, 32), "dense100": (100, 80)}[name]
+            A, b, c = problems.random_dense_arrays(m_, n_, B, seed=0, shard=rank)
+            Ae, be, ce = problems.equality_arrays(A, b, c)
+            lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
+            solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, reserve_cus=reserve)
+            cfg = {"dense3": "BASELINE.json configs[2]", "dense2": "BASELINE.json configs[1]",
+                   "dense100": "a dense LP beyond the lane-group kernels; m = 100 is the reference's own kernel-test size, "
+                               "tests/test_ldl.py:226-238"}[name]
+            self.what = ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, A~U[0,1) shared, "
+                         "b,c~U[0.5,1.5), seed 0 (%s)" % (B, m_, n_, n_ + m_, cfg))
+        self.m, self.n, self.N = m_, n_, n_ + m_
+        self.A, self.b_std, self.c_std = A, b, c
+        self.lp, self.solver = lp, solver
+        lp.init(solver)
+        if self.per_a:      # the values travel once, like b and c: resident in HBM when the timed region starts
+            solver._a_values = torch.as_tensor(np.ascontiguousarray(np.asarray(lp.A.data, dtype=np.float64)[:, solver._a_perm]), device=dev)
+        self.bd = torch.as_tensor(be, device=dev)
+        self.cd = torch.as_tensor(ce, device=dev)
+
+    def step(self, slot=0):
+        return self.solver.solve_device(self.bd, self.cd, slot=slot)
+
+    # -- parity on the committed golden LPs (outputs of the reference's CPU solver; outside any timed region) ----------
+    def parity(self):
+        import torch
+        from pycllp_amd import problems
+        s, dev = self.solver, self.dev
+        fname = {"dense3": "config_32x64.npz", "dense2": "config_16x32.npz", "dense100": "config_dense_100x80.npz",
+                 "sparse5": "config_sparse_128x256.npz", "perA": "config_perA_128x256.npz"}[self.name]
+        path = os.path.join(GOLDEN, fname)
+        if not os.path.exists(path):
+            return None
+        g = np.load(path)
+        if self.per_a:
+            k = int(g["nobj"])       # the first LPs of the batch ARE the golden LPs (values: problems.per_problem_values, seed 7)
+            assert np.allclose(g["input_checksum"], [self.coo[2][:k].sum(), self.b_std[:k].sum(), self.c_std[:k].sum()], rtol=1e-12)
+            keep = s._a_values
+            s._a_values = keep[:k].contiguous()
+            try:
+                r = s.solve_device(self.bd[:k].contiguous(), self.cd[:k].contiguous(), slot=2)
+                torch.cuda.synchronize(dev)
+            finally:
+                s._a_values = keep
+            src = ("reference ipo.py (hsd.c) called LP by LP with each LP's own matrix, via tests/golden/%s (the reference's LP "
+                   "classes refuse a per-problem-A batch, lp.py:335-336; its solver takes one matrix per call)" % fname)
+        elif self.sparse:
+            k = int(g["pobj"].shape[0])
+            r = s.solve_device(g["b"], np.hstack([g["c"], np.zeros((k, self.m))]), slot=2)
+            torch.cuda.synchronize(dev)
+            src = "reference ipo.py (hsd.c) via tests/golden/%s" % fname
+        else:
+            k = int(g["nobj"])
+            A2, b2, c2 = problems.random_dense_arrays(self.m, self.n, k, seed=0)
+            assert np.allclose(g["input_checksum"], [A2.sum(), b2.sum(), c2.sum()], rtol=1e-12)
+            _, b2e, c2e = problems.equality_arrays(A2, b2, c2)
+            r = s.solve_device(b2e, c2e, slot=2)
+            torch.cuda.synchronize(dev)
+            src = "reference ipo.py (hsd.c) via tests/golden/%s" % fname
+        ep = np.abs(r["pobj"].cpu().numpy() - g["pobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+        ed = np.abs(r["dobj"].cpu().numpy() - g["dobj"]) / np.maximum(1.0, np.abs(g["dobj"]))
+        return {"golden_lps": k, "max_rel_err_primal_obj": float(ep.max()), "max_rel_err_dual_obj": float(ed.max()),
+                "tolerance": 1e-8, "ok": bool(ep.max() <= 1e-8 and ed.max() <= 1e-8 and (r["status"].cpu().numpy() == 0).all()),
+                "source": src}
+
+    # -- roofline of the dominant kernel ----------------------------------------------------------------------------------
+    def roofline(self, kern_ms, iters_mean, world=1):
+        import scipy.sparse as sp
+        m_, n_, Nn, B = self.m, self.n, self.N, self.B
+        if self.sparse:
+            nnz_e = int(self.A.nnz) + m_
+            coln = np.diff(sp.csc_matrix(self.lp.A.tocsr(0) if self.per_a else self.lp.A.tocsr()).indptr)
+            n_terms = int((coln * (coln + 1) // 2).sum())
+            f_alg = f_exec = flops_per_lp_sparse(m_, Nn, iters_mean, n_terms, nnz_e)
+        else:
+            f_alg = flops_per_lp(m_, Nn, iters_mean)
+            # executed work: the slack-aware kernels (lane-group kernel and the dense-image wave kernel alike) run the Gram
+            # product and the mat-vecs on the n = N - m dense columns only (the identity columns of [A | I] bypass them)
+            f_exec = iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
+        t = kern_ms * 1e-3
+        tf_alg, tf_exec = f_alg * B / t / 1e12, f_exec * B / t / 1e12
+        a_bytes = 8 * (int(self.A.nnz) + m_) if self.per_a else 0   # per-problem A: every LP reads its own values (equality form)
+        b_survey = 16 * (m_ + Nn) + 24 + a_bytes                    # SURVEY 8d: b, c in; x, y out; objectives; status, iters
+        b_with_z = bytes_per_lp(m_, Nn) + a_bytes                   # + the dual slacks z this library also returns
+        gbs = b_survey * B / t / 1e9
+        # HBM traffic of the dominant kernel from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+        # passes): a profile-sourced figure, attached only when this run is the profiled configuration
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            ent = json.load(open(tpath)).get(self.name + ("_hsd" if self.hsd else ""))
+            if ent and ent.get("lps_per_launch") == B and world == 1:
+                traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
+        return {"bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf_exec / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel_ms": kern_ms, "flop_per_lp": f_exec,
+                "frac_algorithmic": tf_alg / PEAK_FP64_TFLOPS, "achieved_algorithmic": tf_alg, "flop_per_lp_algorithmic": f_alg,
+                "note": "FP64 FMA/MFMA peak.  achieved / frac: the flops the kernel EXECUTES with the measured mean iteration "
+                        "count, refinement passes counted as 0 (dense workloads: the identity columns of [A | I] are never "
+                        "multiplied; sparse workloads: term-list Gram + CSR products + dense m^3/3 LDL').  frac_algorithmic: "
+                        "SURVEY 8d's formula, which prices every column of the equality form densely (rounds 1-2 reported "
+                        "that figure as frac; ADVICE r2)",
+                "hbm_algorithmic": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                    "bytes_per_lp": b_survey, "bytes_per_lp_with_z": b_with_z}}
+
+    def kernel_name(self, info):
+        if self.sparse or "kernel" in info:
+            if info.get("kernel") == "wave":
+                return ("%s (one LP per wavefront, factor in registers, A as %s)%s, grid %d x block %d, %d B LDS"
+                        % ("hsd_wreg_kernel" if self.hsd else "ipm_wreg_kernel", info.get("variant", "tables"),
+                           ", PYCLLP_FLAG_HSD" if self.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
+            return ("ipm_block_kernel (one LP per 256-thread workgroup)%s, grid %d x block %d, %d B LDS"
+                    % (", PYCLLP_FLAG_HSD" if self.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
+        return ("%s<%d,%d> grid %d x block %d, %d B LDS" % ("hsd_group_kernel" if self.hsd else "ipm_group_kernel",
+                                                            info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"]))
+
+    def launch_info(self):
+        return self.solver.launch_info()
+
+    def cpu(self, seconds):
+        import scipy.sparse as sp
+        if self.per_a:
+            rows, cols, data = self.coo
+            shape = (self.m, self.n)
+            return cpu_reference(lambda k: sp.csr_matrix((data[k], (rows, cols)), shape=shape), self.b_std, self.c_std, seconds,
+                                 "this workload, each with its own matrix")
+        return cpu_reference(self.A, self.b_std, self.c_std, seconds, "this workload",
+                             chunk=256 if self.m <= 32 else 16)
+
+
+def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None):
+    """One secondary record: the workload resident in HBM, `warmup` untimed and `steps` timed passes (HIP events around
+    every launch on the launch stream, wall clock between two device synchronisations), parity, roofline, CPU reference."""
+    import torch
+    t_build = time.perf_counter()
+    w = Workload(name, B, 0, dev, hsd=hsd)
+    for k in range(warmup):
+        w.step(k % 2)
+    torch.cuda.synchronize(dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        buf = w.step(k % 2)
+        ev[k][1].record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+    info = w.launch_info()
+    status = buf["status"].cpu().numpy(); iters = buf["iters"].cpu().numpy()
+    pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
+    rec = {"workload": name + ("_hsd" if hsd else ""), "value": B * steps / elapsed, "unit": "LPs/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kern_ms,
+           "config": {"workload": w.what, "lps_per_gpu": B, "m": w.m, "n": w.n, "N_equality": w.N, "kernel": w.kernel_name(info)},
+           "solved_optimal": int((status == 0).sum()), "mean_ipm_iterations": float(iters.mean()),
+           "max_rel_duality_gap": float(np.max(np.abs(pobj - dobj) / np.maximum(1.0, np.abs(pobj)))),
+           "parity": w.parity(), "roofline": w.roofline(kern_ms, float(iters.mean()))}
+    rec["cpu_baseline"] = cpu_from if cpu_from is not None else (w.cpu(cpu_seconds) if cpu_seconds else None)
+    rec["record_seconds"] = time.perf_counter() - t_build
+    return rec
+
+
+SECONDARY = (("dense2", 4096, False), ("sparse5", 16384, False), ("sparse5", 16384, True), ("perA", 16384, False),
+             ("dense100", 16384, False))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +337,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="LPs per GPU (default: the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hsd", action="store_true", help="sparse5 only: time the homogeneous self-dual variant (PYCLLP_FLAG_HSD)")
-    ap.add_argument("--workload", choices=("dense3", "sparse5", "perA"), default="dense3",
+    ap.add_argument("--no-secondary", action="store_true", help="headline record only (no `secondary` list)")
+    ap.add_argument("--hsd", action="store_true", help="time the homogeneous self-dual variant (PYCLLP_FLAG_HSD) of --workload")
+    ap.add_argument("--workload", choices=("dense3", "sparse5", "perA", "dense2", "dense100"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
-                         "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal")
+                         "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal; perA: "
+                         "the same with per-problem values of A; dense2: configs[1]; dense100: 16 384 dense LPs (m=100, n=80)")
     ap.add_argument("--sync-gather", action="store_true", help="block on the result gather after every solve (no overlap)")
     ap.add_argument("--reserve-cus", type=int, default=None,
                     help="compute units the solve kernel leaves idle (opts.reserve_cus).  Default: 8 (one per XCD) when "
@@ -133,9 +364,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pycllp_amd import problems
-    from pycllp_amd.lp import SparseMatrix, EqualityLP
-    from pycllp_amd.solvers import solver_registry
     from pycllp_amd.dist import PackedGather
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,51 +389,22 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    B = args.batch
+    if args.batch == B_PER_GPU and args.workload != "dense3":
+        B = 4096 if args.workload == "dense2" else 16384
+    wl = Workload(args.workload, B, rank, dev, reserve=reserve, hsd=args.hsd)
+    solver, bd, cd, Nn = wl.solver, wl.bd, wl.cd, wl.N
+    sparse, per_a, m_, n_ = wl.sparse, wl.per_a, wl.m, wl.n
+
     cpu = cpu_all = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-        cpu_all = cpu_port(cpu["value"] if cpu["kind"] == "reference" else None)
-
-    B = args.batch
-    per_a = args.workload == "perA"       # one structure, every LP its own values of A (read from HBM per LP)
-    sparse = args.workload == "sparse5" or per_a
-    if sparse:
-        if args.batch == B_PER_GPU:
-            B = 16384
-        m_, n_ = 128, 256
-        A, b, c = problems.random_sparse_arrays(m_, n_, B, density=0.025, seed=0)
-        if rank:
-            rs = np.random.RandomState(1000003 * rank)
-            b = 0.5 + rs.rand(B, m_); c = 0.5 + rs.rand(B, n_)
-        be, ce = b, np.hstack([c, np.zeros((B, m_))])
-        Nn = n_ + m_
-        from pycllp_amd.lp import StandardLP
-        if per_a:
-            # the structure of configs[4]'s A, values of LP k = the shared ones x U[0.75, 1.25) per entry (seed 7 + rank)
-            Ac = A.tocoo()
-            data = Ac.data[None, :] * (0.75 + 0.5 * np.random.RandomState(7 + rank).rand(B, Ac.nnz))
-            lp = StandardLP(SparseMatrix(Ac.row, Ac.col, data), b, c, 0.0).to_equality_form()
+        if args.workload == "dense3":
+            cpu = cpu_baseline()
+            cpu_all = cpu_port(cpu["value"] if cpu["kind"] == "reference" else None)
         else:
-            lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
-        # the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto' runs first;
-        # --hsd: the homogeneous self-dual variant (41 instead of 52 iterations on this workload, two solves per iteration)
-        solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=bool(args.hsd), reserve_cus=reserve)
-        cpu = None
-    else:
-        m_, n_ = M, N_STD
-        A, b, c = problems.random_dense_arrays(M, N_STD, B, seed=0, shard=rank)
-        Ae, be, ce = problems.equality_arrays(A, b, c)
-        Nn = Ae.shape[1]
-        lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
-        solver = solver_registry["hip_dense_primal_normal"](device=dev, reserve_cus=reserve)
-    lp.init(solver)
-    if per_a:      # the values travel once, like b and c: resident in HBM when the timed region starts
-        solver._a_values = torch.as_tensor(np.ascontiguousarray(np.asarray(lp.A.data, dtype=np.float64)[:, solver._a_perm]), device=dev)
-    bd = torch.as_tensor(be, device=dev)
-    cd = torch.as_tensor(ce, device=dev)
-    sizes = [B] * world
-    fields = ("pobj", "dobj", "status", "iters", "x", "y")
+            cpu = wl.cpu(8.0)
 
+    fields = ("pobj", "dobj", "status", "iters", "x", "y")
     # Result gather to rank 0 (the path's one collective).  It is issued asynchronously and overlaps the NEXT step's
     # solve: outputs are double-buffered (slot k%2), receive buffers on rank 0 too, and a slot is reused only after the
     # gather that read it has completed.  --sync-gather falls back to a blocking gather after every solve.
@@ -255,7 +454,7 @@ def main():
     gathered = pg.results(args.steps - 1, names=fields) if multi else None
 
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
-    info = solver.launch_info()      # of the timed launches (the parity solve below launches again, with another batch)
+    info = wl.launch_info()      # of the timed launches (the parity solve below launches again, with another batch)
     status = buf["status"].cpu().numpy()
     iters = buf["iters"].cpu().numpy()
     pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
@@ -274,111 +473,39 @@ def main():
         ok_total, iters_mean = ok_local, float(iters.mean())
 
     if rank == 0:
-        # parity on the committed golden LPs (outside the timed region)
-        parity = None
-        gpath = os.path.join(ROOT, "tests", "golden", "config_32x64.npz")
-        if sparse:
-            import scipy.sparse as sp
-        if per_a:
-            # no reference fixture can exist for this extension (the reference's LP classes refuse per-problem A, lp.py:335-336)
-            # and the oracle belongs to tests/ (tests/test_hip_parity.py::test_per_problem_values_of_A checks every LP against
-            # it with ITS OWN matrix): here the first LPs are checked through the optimality conditions themselves
-            kk = 64
-            xs = buf["x"][:kk].cpu().numpy(); ys = buf["y"][:kk].cpu().numpy(); zs = buf["z"][:kk].cpu().numpy()
-            pv = buf["pobj"][:kk].cpu().numpy(); dv = buf["dobj"][:kk].cpu().numpy()
-            rp = rd = 0.0
-            for k in range(kk):
-                Ak = np.asarray(lp.A.todense(k))
-                rp = max(rp, np.linalg.norm(be[k] - Ak @ xs[k]) / (1.0 + np.linalg.norm(be[k])))
-                rd = max(rd, np.linalg.norm(ce[k] - Ak.T @ ys[k] + zs[k]) / (1.0 + np.linalg.norm(ce[k])))
-            parity = {"kkt_lps": kk, "max_rel_primal_residual": float(rp), "max_rel_dual_residual": float(rd),
-                      "max_rel_gap": float(np.max(np.abs(pv - dv) / np.maximum(1.0, np.abs(pv)))), "tolerance": 1e-8,
-                      "source": "optimality conditions with each LP's own matrix (parity unpinned by the reference: it has no "
-                                "per-problem-A path; oracle parity LP by LP is in tests/test_hip_parity.py)"}
-        elif sparse:
-            g = np.load(os.path.join(ROOT, "tests", "golden", "config_sparse_128x256.npz"))
-            r = solver.solve_device(g["b"], np.hstack([g["c"], np.zeros((g["c"].shape[0], m_))]))
-            torch.cuda.synchronize(dev)
-            ep = np.abs(r["pobj"].cpu().numpy() - g["pobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
-            ed = np.abs(r["dobj"].cpu().numpy() - g["dobj"]) / np.maximum(1.0, np.abs(g["dobj"]))
-            parity = {"golden_lps": int(g["pobj"].shape[0]), "max_rel_err_primal_obj": float(ep.max()),
-                      "max_rel_err_dual_obj": float(ed.max()), "tolerance": 1e-8,
-                      "source": "reference ipo.py (hsd.c) via tests/golden/config_sparse_128x256.npz"}
-        elif os.path.exists(gpath):
-            g = np.load(gpath)
-            A2, b2, c2 = problems.random_dense_arrays(M, N_STD, int(g["nobj"]), seed=0)
-            _, b2e, c2e = problems.equality_arrays(A2, b2, c2)
-            r = solver.solve_device(b2e, c2e)
-            torch.cuda.synchronize(dev)
-            ep = np.abs(r["pobj"].cpu().numpy() - g["pobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
-            ed = np.abs(r["dobj"].cpu().numpy() - g["dobj"]) / np.maximum(1.0, np.abs(g["dobj"]))
-            parity = {"golden_lps": int(g["nobj"]), "max_rel_err_primal_obj": float(ep.max()),
-                      "max_rel_err_dual_obj": float(ed.max()), "tolerance": 1e-8,
-                      "source": "reference ipo.py (hsd.c) via tests/golden/config_32x64.npz"}
+        parity = wl.parity()     # on the committed golden LPs (outside the timed region)
         total = B * world * args.steps
         value = total / elapsed
-        if sparse:   # term-list Gram assembly and CSR/CSC products instead of the dense m(m+1)N + 8mN
-            nnz_e = int(A.nnz) + m_
-            coln = np.diff(sp.csc_matrix(lp.A.tocsr()).indptr)
-            n_terms = int((coln * (coln + 1) // 2).sum())
-            f_lp = iters_mean * (2 * n_terms + 8 * nnz_e + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
-        else:
-            f_lp = flops_per_lp(m_, Nn, iters_mean)
-        tflops = f_lp * B / (kern_ms * 1e-3) / 1e12
-        # executed work: the slack-aware dense kernel runs the Gram product and the mat-vecs on the n = N - m dense
-        # columns only (the identity columns of [A | I] bypass them); the sparse formula above already counts executed work
-        f_exec = f_lp if sparse else iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
-        tflops_exec = f_exec * B / (kern_ms * 1e-3) / 1e12
-        a_bytes = 8 * (int(A.nnz) + m_) if per_a else 0      # per-problem A: every LP reads its own values (equality form)
-        b_survey = 16 * (m_ + Nn) + 24 + a_bytes             # b, c in; x, y out; objectives; status, iters
-        b_with_z = bytes_per_lp(m_, Nn) + a_bytes            # + the dual slacks z this library also returns
-        gbs = b_survey * B / (kern_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel from PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-        # passes): a profile-sourced figure, attached only when this run is the profiled configuration
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            ent = tj.get(args.workload)
-            if ent and ent.get("lps_per_launch") == B and world == 1 and not args.hsd:
-                traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
         out = {
             "metric": "LPs solved/sec", "value": value, "unit": "LPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.rehearse else "synthetic (REHEARSAL on one shared GPU: not a result)",
-            "config": {"workload": ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 "
-                                    "non-zeros) -> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)%s"
-                                    % (B, m_, n_, Nn, "; PER-PROBLEM VALUES of A on that structure (SURVEY 8f-4; shared x U[0.75,1.25))"
-                                       if per_a else "")) if sparse else
-                                   ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, "
-                                    "A~U[0,1) shared, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[2]%s)"
-                                    % (B, M, N_STD, Nn, "; x8 = configs[3]" if world == 8 else "")),
+            "config": {"workload": wl.what + ("; x8 = configs[3]" if (world == 8 and args.workload == "dense3") else ""),
                        "lps_per_gpu": B, "lps_total": B * world, "m": m_, "n": n_, "N_equality": Nn,
                        "parallelism": "batch sharded over %d GPU(s), result gather to rank 0" % world, "reserve_cus": reserve,
-                       "kernel": ("%s%s, grid %d x block %d, %d B LDS"
-                                  % (("hsd_wreg_kernel" if args.hsd else "ipm_wreg_kernel") + " (one LP per wavefront, factor in registers)"
-                                     if info["kernel"] == "wave" else "ipm_block_kernel (one LP per 256-thread workgroup)",
-                                     ", PYCLLP_FLAG_HSD" if args.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
-                                 if sparse else
-                                 "ipm_group_kernel<%d,%d> grid %d x block %d, %d B LDS"
-                                 % (info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"])},
+                       "kernel": wl.kernel_name(info)},
             "solved_optimal": ok_total, "mean_ipm_iterations": iters_mean, "max_rel_duality_gap_rank0": gap,
             "parity": parity,
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel_ms": kern_ms, "flop_per_lp": f_lp,
-                         "frac_executed": tflops_exec / PEAK_FP64_TFLOPS, "flop_per_lp_executed": f_exec,
-                         "note": "FP64 FMA/MFMA peak.  frac: algorithmic flops of SURVEY 8d (every column of the equality "
-                                 "form priced densely; sparse workload: term-list Gram + CSR products + dense m^3/3 LDL') with "
-                                 "the measured mean iteration count, refinement passes counted as 0.  frac_executed: the "
-                                 "flops the kernel executes (dense workload: identity columns excluded)",
-                         "hbm_algorithmic": {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                             "frac": gbs / PEAK_HBM_GBS, "bytes_per_lp": b_survey,
-                                             "bytes_per_lp_with_z": b_with_z}},
+            "roofline": wl.roofline(kern_ms, iters_mean, world),
             "cpu_baseline": cpu,
             "cpu_port": cpu_all,
         }
+        if world == 1 and not multi and args.workload == "dense3" and not args.hsd and not args.no_secondary and B == B_PER_GPU:
+            # the other single-GPU configurations under the same clock (records; `value` above stays the headline's)
+            del wl
+            sec, cpu5 = [], None
+            for name, Bs, hsd in SECONDARY:
+                try:
+                    reuse = cpu5 if (name == "sparse5" and hsd) else None     # same LPs, same reference solver: timed once
+                    r = measure_secondary(name, Bs, dev, steps=5, warmup=2, hsd=hsd,
+                                          cpu_seconds=None if args.no_cpu_baseline else 4.0, cpu_from=reuse)
+                    if name == "sparse5" and not hsd:
+                        cpu5 = r["cpu_baseline"]
+                    sec.append(r)
+                except Exception as exc:      # a secondary record must never cost the headline its line
+                    sec.append({"workload": name + ("_hsd" if hsd else ""), "error": "%s: %s" % (type(exc).__name__, exc)})
+            out["secondary"] = sec
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:

@@ -76,6 +76,10 @@ extern "C" {
 #define PYCLLP_FLAG_WAVE_KERNEL 2 /* use the first-generation kernel (one LP per wavefront) instead
                                      of the default one (one LP per 16/32-lane group)          */
 
+#define PYCLLP_MAX_REFINE_AUTO (-1)
+#define PYCLLP_MAX_REFINE_PLAIN 5
+#define PYCLLP_MAX_REFINE_HSD 20
+
 typedef struct pycllp_hip_opts {
     double eps;         /* relative stopping tolerance on |rho|,|sigma|,gamma; default 1e-10.
                            (reference: absolute EPS 1e-7f, primal_normal.cl:8,256)           */
@@ -85,7 +89,9 @@ typedef struct pycllp_hip_opts {
     double refine_tol;  /* refinement tolerance on max|b-Ax-A dx|, relative to 1+|b|, default
                            1e-11 (reference: 1e-8 absolute on rhs-M dy, ldl.cl:645)          */
     int max_iter;       /* default 200 (primal_normal.cl:9)                                  */
-    int max_refine;     /* default 5 (ldl.cl:645); with PYCLLP_FLAG_HSD use 20   */
+    int max_refine;     /* refinement passes per Newton system.  Default PYCLLP_MAX_REFINE_AUTO (-1): resolved inside
+                           every entry point to 5 (ldl.cl:645) on the reference's path and to 20 with PYCLLP_FLAG_HSD
+                           (DESIGN.md section 9); any value >= 0 is taken as given               */
     int flags;          /* PYCLLP_FLAG_*                                                     */
     int reserve_cus;    /* compute units the solve leaves idle (default 0).  The solve kernels are persistent and fill every CU
                            completely (LDS and registers), so a kernel on another stream -- e.g. the RCCL copy kernels of the
@@ -127,6 +133,11 @@ int pycllp_hip_dense_newton(pycllp_hip_dense *handle, long B, const double *x_de
 /* Kernel-level statistics of the last solve launch on this handle (host values). */
 int pycllp_hip_dense_launch_info(const pycllp_hip_dense *handle, int *grid, int *block, int *lds_bytes,
                                  int *m_pad, int *n_pad);
+
+/* Which kernel family serves this handle: -1 = the lane-group kernels (m <= 32, n <= 128); otherwise the LP was handed to
+ * the sparse path's kernels at init and the value is that of pycllp_hip_sparse_launch_info's `kernel` for the last launch
+ * (0 = workgroup-per-LP block kernel, 1 = wavefront-per-LP kernel on term tables, 2 = the same on a dense image of A). */
+int pycllp_hip_dense_kernel_kind(const pycllp_hip_dense *handle);
 
 void pycllp_hip_dense_free(pycllp_hip_dense *handle);
 

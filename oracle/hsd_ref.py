@@ -44,17 +44,30 @@ def dense_to_csc(A):
     return vals, iA, kA
 
 
+def sparse_to_csc(A):
+    """scipy sparse [m,n] -> (values, row indices, column pointers) of its structural non-zeros: what the reference's
+    ``SparseMatrix.tocsc_arrays`` hands the solver for a sparse A (lp.py:289-299 walks the stored entries only)."""
+    import scipy.sparse as sp
+    C = sp.csc_matrix(A)
+    C.sort_indices()
+    return (np.ascontiguousarray(C.data, dtype=np.float64), np.ascontiguousarray(C.indices, dtype=np.int32),
+            np.ascontiguousarray(C.indptr, dtype=np.int32))
+
+
 def solve_standard(A, b, c, f=0.0):
-    """Solve the batch of StandardLPs max c_i'x s.t. A x <= b_i, x >= 0 one by one.
+    """Solve the batch of StandardLPs max c_i'x s.t. A x <= b_i, x >= 0 one by one.  ``A``: dense array (every entry is
+    handed over, as for a dense reference LP) or a scipy sparse matrix (structural non-zeros only).
 
     Returns dict(x[B,n], y[B,m], w[B,m], z[B,n], pobj, dobj, status)."""
     L = lib()
-    A = np.asarray(A, dtype=np.float64)
+    sparse = hasattr(A, "tocsc")
+    if not sparse:
+        A = np.asarray(A, dtype=np.float64)
     b = np.ascontiguousarray(np.atleast_2d(b), dtype=np.float64)
     c = np.ascontiguousarray(np.atleast_2d(c), dtype=np.float64)
     m, n = A.shape
     B = b.shape[0]
-    vals, iA, kA = dense_to_csc(A)
+    vals, iA, kA = sparse_to_csc(A) if sparse else dense_to_csc(A)
     x = np.empty((B, n)); y = np.empty((B, m)); w = np.empty((B, m)); z = np.empty((B, n))
     status = np.empty(B, dtype=np.int32)
     P = lambda a: a.ctypes.data_as(_dp)

@@ -15,7 +15,7 @@ EXPORTS = (
     "pycllp_hip_abi_version", "pycllp_hip_last_error", "pycllp_hip_default_opts",
     "pycllp_hip_dense_max_rows", "pycllp_hip_dense_max_cols", "pycllp_hip_dense_init",
     "pycllp_hip_dense_solve", "pycllp_hip_dense_newton", "pycllp_hip_dense_launch_info",
-    "pycllp_hip_dense_free", "pycllp_hip_ldl",
+    "pycllp_hip_dense_free", "pycllp_hip_ldl", "pycllp_hip_dense_kernel_kind",
     "pycllp_hip_sparse_max_rows", "pycllp_hip_sparse_max_cols", "pycllp_hip_sparse_init", "pycllp_hip_sparse_solve",
     "pycllp_hip_sparse_free", "pycllp_hip_sparse_newton", "pycllp_hip_sparse_launch_info",
     "pycllp_hip_ldl_solve", "pycllp_hip_forward_backward_ldl", "pycllp_hip_sparse_solve_batch",
@@ -64,6 +64,8 @@ def lib():
     L.pycllp_hip_dense_newton.restype = ctypes.c_int
     L.pycllp_hip_dense_launch_info.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int)] * 5
     L.pycllp_hip_dense_launch_info.restype = ctypes.c_int
+    L.pycllp_hip_dense_kernel_kind.argtypes = [vp]
+    L.pycllp_hip_dense_kernel_kind.restype = ctypes.c_int
     L.pycllp_hip_ldl.argtypes = [ctypes.c_int, ctypes.c_long, dp, dp, dp, ctypes.c_int, ctypes.c_double, ctypes.c_double, vp]
     L.pycllp_hip_ldl.restype = ctypes.c_int
     L.pycllp_hip_sparse_max_rows.restype = ctypes.c_int
@@ -97,8 +99,9 @@ def lib():
 # The homogeneous self-dual variant is this package's addition and its systems are harder near the end: with a cap of 5
 # the degenerate LP 7557 of config 5's share sits at a 1.6e-10 relative gap for 70-150 iterations (oracle: 118 in all,
 # the kernels 58-200 depending on rounding), with 10 passes it needs 48 iterations, with 20 passes 39.  No other LP of
-# the test workloads uses more than 5.
-HSD_MAX_REFINE = 20
+# the test workloads uses more than 5.  The choice is made INSIDE the library (pycllp_hip_opts.max_refine = -1 = "auto",
+# what pycllp_hip_default_opts returns: 5 on the plain path, 20 with PYCLLP_FLAG_HSD), so a C caller gets it too.
+MAX_REFINE_AUTO, HSD_MAX_REFINE = -1, 20
 
 
 def default_opts(**kw):
@@ -108,8 +111,6 @@ def default_opts(**kw):
         if k not in dict(Opts._fields_):
             raise TypeError("unknown solver option %r" % k)
         setattr(o, k, v)
-    if "max_refine" not in kw and (o.flags & FLAG_HSD):
-        o.max_refine = HSD_MAX_REFINE
     return o
 
 

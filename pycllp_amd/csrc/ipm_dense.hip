@@ -342,8 +342,11 @@ struct Wave {
 };
 
 // ------------------------------------------------------------------------------------------------
-// solve kernel: standard_primal_normal (primal_normal.cl:201-284), one LP per wavefront, persistent
+// solve kernel: standard_primal_normal (primal_normal.cl:201-284), one LP per wavefront, persistent.
+// FIRST GENERATION (round 1), superseded by ipm_group_kernel: compiled only with -DPYCLLP_FIRST_GEN (diagnostic A/B
+// builds); the default library answers PYCLLP_FLAG_WAVE_KERNEL with PYCLLP_E_UNSUPPORTED.
 // ------------------------------------------------------------------------------------------------
+#ifdef PYCLLP_FIRST_GEN
 template <int MP, int NP>
 __global__ void __launch_bounds__(512)
 ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const double* __restrict__ bg,
@@ -472,6 +475,7 @@ ipm_solve_kernel(int m, int n, long B, const double* __restrict__ pack, const do
     }
     STAMP_FLUSH(o, blockIdx.x * wpb + wave)
 }
+#endif  // PYCLLP_FIRST_GEN
 
 // ------------------------------------------------------------------------------------------------
 // stand-alone Newton step kernel: solve_primal_normal (ldl.cl:602-653) as launched by the reference's
@@ -645,19 +649,23 @@ static hipError_t launch_pack(pycllp_hip_dense* h, const double* A, hipStream_t 
     return hipGetLastError();
 }
 
+#ifdef PYCLLP_FIRST_GEN
 template <int MP, int NP>
 static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
                                double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                hipStream_t st) {
     const LaunchPlan p = plan<MP, NP>(h, B);
-    hipError_t e = hipFuncSetAttribute((const void*)ipm_solve_kernel<MP, NP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
+    hipError_t e = set_dyn_lds((const void*)ipm_solve_kernel<MP, NP>, p.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ipm_solve_kernel<MP, NP>), dim3(p.grid), dim3(p.block), p.lds, st, h->m, h->n, B,
                        h->pack, b, c, x, y, z, pobj, dobj, status, iters, o);
     publish(h, p);
     return hipGetLastError();
 }
+#define FIRST_GEN_SOLVE(MP, NP) launch_solve<MP, NP>
+#else
+#define FIRST_GEN_SOLVE(MP, NP) nullptr
+#endif
 
 template <int MP, int NP, bool SL, bool HSD = false>
 static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
@@ -675,7 +683,7 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     if (blocks < 1) blocks = 1;
     const LaunchPlan p{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
     auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL>;
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
+    hipError_t e = set_dyn_lds((const void*)kernel, p.lds);
     if (e != hipSuccess) return e;
     int* qhead = nullptr; unsigned slot = 0;
     e = h->ring.acquire(st, &qhead, &slot);
@@ -693,8 +701,7 @@ static hipError_t launch_newton(pycllp_hip_dense* h, long B, const double* x, co
                                 const double* b, const double* c, double mu, double* dy, int* nref, DevOpts o,
                                 hipStream_t st) {
     const LaunchPlan p = plan<MP, NP>(h, B);
-    hipError_t e = hipFuncSetAttribute((const void*)newton_kernel<MP, NP>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, p.lds);
+    hipError_t e = set_dyn_lds((const void*)newton_kernel<MP, NP>, p.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((newton_kernel<MP, NP>), dim3(p.grid), dim3(p.block), p.lds, st, h->m, h->n, B,
                        h->pack, x, z, y, b, c, mu, dy, nref, o);
@@ -711,7 +718,7 @@ struct Variant {
 };
 
 #define VARIANT(MP, NP) \
-    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, launch_solve<MP, NP>, launch_solve_group<MP, NP, false>, \
+    { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, FIRST_GEN_SOLVE(MP, NP), launch_solve_group<MP, NP, false>, \
       launch_solve_group<MP, NP, false, true>, launch_newton<MP, NP> }
 
 // ordered by cost: the first variant that covers (m, n) is used
@@ -741,7 +748,10 @@ static DevOpts to_dev(const pycllp_hip_opts* opts) {
     if (opts) d = *opts;
     DevOpts o;
     o.eps = d.eps; o.delta = d.delta; o.r = d.r; o.pivot_floor = d.pivot_floor; o.refine_tol = d.refine_tol;
-    o.max_iter = d.max_iter; o.max_refine = d.max_refine; o.flags = d.flags;
+    o.max_iter = d.max_iter; o.flags = d.flags;
+    // PYCLLP_MAX_REFINE_AUTO: the reference's cap of 5 passes (ldl.cl:645) on its own path; 20 on the homogeneous self-dual
+    // variant, whose last systems are harder (with 5, LP 7557 of config 5's share stalls for 70-150 iterations)
+    o.max_refine = d.max_refine >= 0 ? d.max_refine : ((d.flags & PYCLLP_FLAG_HSD) ? PYCLLP_MAX_REFINE_HSD : PYCLLP_MAX_REFINE_PLAIN);
     o.reserve_cus = d.reserve_cus < 0 ? 0 : d.reserve_cus;
     o.prof = g_prof;
     return o;
@@ -782,7 +792,7 @@ void pycllp_hip_default_opts(pycllp_hip_opts* o) {
     o->pivot_floor = 1e-6;
     o->refine_tol = 1e-11;
     o->max_iter = 200;
-    o->max_refine = 5;
+    o->max_refine = PYCLLP_MAX_REFINE_AUTO;
     o->flags = 0;
     o->reserve_cus = 0;
 }
@@ -902,8 +912,11 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
     const Variant& v = kVariants[h->variant];
     const bool hsd = (o.flags & PYCLLP_FLAG_HSD) != 0;
     solve_launch_fn fn = hsd ? v.solve_hsd : v.solve_group;
-    if (o.flags & PYCLLP_FLAG_WAVE_KERNEL) fn = v.solve;
-    else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH))
+    if (o.flags & PYCLLP_FLAG_WAVE_KERNEL) {
+        fn = v.solve;
+        if (!fn) return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_dense_solve: the first-generation kernel (PYCLLP_FLAG_WAVE_KERNEL) is not "
+                                                      "part of this build (diagnostic builds: make EXTRA=-DPYCLLP_FIRST_GEN)");
+    } else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH))
         fn = hsd ? kSlackVariants[h->variant_sl].solve_hsd : kSlackVariants[h->variant_sl].solve_group;
     hipError_t e = fn(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o,
                       (hipStream_t)stream);
@@ -945,6 +958,13 @@ int pycllp_hip_dense_launch_info(const pycllp_hip_dense* h, int* grid, int* bloc
     return 0;
 }
 
+int pycllp_hip_dense_kernel_kind(const pycllp_hip_dense* h) {
+    if (!h || !h->sp) return -1;
+    int kern = 0;
+    if (pycllp_hip_sparse_launch_info(h->sp, nullptr, nullptr, nullptr, &kern) != 0) return -1;
+    return kern;
+}
+
 int pycllp_hip_ldl(int n, long B, const double* A_dev, double* L_dev, double* D_dev, int modified, double beta,
                    double delta, void* stream) {
     if (n <= 0 || B < 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl: bad argument");
@@ -957,7 +977,7 @@ int pycllp_hip_ldl(int n, long B, const double* A_dev, double* L_dev, double* D_
     if (modified && !(beta > 0.0)) return set_err(PYCLLP_E_BADARG, "pycllp_hip_ldl: beta must be positive");
     const int threads = (n <= 64) ? 64 : 128;
     const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) + 8));
-    hipError_t e = hipFuncSetAttribute((const void*)ldl_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = set_dyn_lds((const void*)ldl_batched_kernel, lds);
     if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(ldl_batched_kernel)");
     long blocks = B < 4096 ? B : 4096;
     hipLaunchKernelGGL(ldl_batched_kernel, dim3((unsigned)blocks), dim3(threads), lds, (hipStream_t)stream, n, B, A_dev,
@@ -1114,7 +1134,7 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
         }
         if (ew != hipSuccess) { (void)hipFreeAsync(worklist, st); return set_err((int)ew, "ipm_wreg_kernel launch"); }
     }
-    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(set_dyn_lds((const void*)ipm_block_kernel, lds));
     const long per_cu = (160 * 1024) / lds >= 4 ? 4 : ((160 * 1024) / lds >= 2 ? 2 : 1);
     const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     long blocks = free_cus * per_cu;
@@ -1166,7 +1186,7 @@ int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, 
         return 0;
     }
     // matrices the wave kernel does not cover (dense, or tables larger than LDS): the block kernel in its Newton mode
-    HIP_TRY(hipFuncSetAttribute((const void*)ipm_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds));
+    HIP_TRY(set_dyn_lds((const void*)ipm_block_kernel, h->lds));
     const long per_cu = (160 * 1024) / h->lds >= 4 ? 4 : ((160 * 1024) / h->lds >= 2 ? 2 : 1);
     long blocks = (long)h->num_cu * per_cu;
     if (blocks > B) blocks = B;
@@ -1213,7 +1233,7 @@ int pycllp_hip_ldl_solve(int n, long B, const double* A_dev, const double* rhs_d
         return 0;
     }
     const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) + n + 8));
-    hipError_t e = hipFuncSetAttribute((const void*)ldl_solve_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = set_dyn_lds((const void*)ldl_solve_batched_kernel, lds);
     if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(ldl_solve_batched_kernel)");
     const long blocks = B < 4096 ? B : 4096;
     hipLaunchKernelGGL(ldl_solve_batched_kernel, dim3((unsigned)blocks), dim3(n <= 64 ? 64 : 128), lds, st, n, B, A_dev, rhs_dev,
@@ -1233,7 +1253,7 @@ int pycllp_hip_forward_backward_ldl(int n, long B, const double* L_dev, const do
         return PYCLLP_E_UNSUPPORTED;
     }
     const int lds = (int)(sizeof(double) * ((size_t)n * (n + 1) / 2 + n + 8));
-    hipError_t e = hipFuncSetAttribute((const void*)forward_backward_ldl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = set_dyn_lds((const void*)forward_backward_ldl_kernel, lds);
     if (e != hipSuccess) return set_err((int)e, "hipFuncSetAttribute(forward_backward_ldl_kernel)");
     const long blocks = B < 4096 ? B : 4096;
     hipLaunchKernelGGL(forward_backward_ldl_kernel, dim3((unsigned)blocks), dim3(n <= 64 ? 64 : 128), lds, (hipStream_t)stream, n, B,

@@ -1798,7 +1798,7 @@ template <int MB, int NQ, bool DA>
 hipError_t do_solve(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
                     double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                     hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)ipm_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)ipm_wreg_kernel<MB, NQ, DA>, T.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
@@ -1808,7 +1808,7 @@ template <int MB, int NQ, bool DA>
 hipError_t do_solve_hsd(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
                         double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                         hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)hsd_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)hsd_wreg_kernel<MB, NQ, DA>, T.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
@@ -1817,7 +1817,7 @@ hipError_t do_solve_hsd(const WregTab& T, long B, const double* b, const double*
 template <int MB, int NQ, bool DA>
 hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z, const double* y, const double* b,
                      const double* c, double mu, double* dy, int* nref, int* qhead, DevOpts o, int grid, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute((const void*)newton_wreg_kernel<MB, NQ, DA>, hipFuncAttributeMaxDynamicSharedMemorySize, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)newton_wreg_kernel<MB, NQ, DA>, T.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((newton_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, x, z, y, b, c, mu, dy,
                        nref, qhead, o);
@@ -2128,7 +2128,7 @@ hipError_t wreg_launch_ldl_solve(int n, long B, const double* A, const double* r
     long grid = std::min((long)num_cu, (B + 3) / 4);
     if (grid < 1) grid = 1;
     const int lds = (int)(sizeof(double) * 4 * WGeo<8>::WAVE_D(1));
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ldl_solve_wreg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = set_dyn_lds((const void*)ldl_solve_wreg_kernel<8>, lds);
     if (e == hipSuccess) {
         hipLaunchKernelGGL((ldl_solve_wreg_kernel<8>), dim3((unsigned)grid), dim3(256), lds, st, n, B, A, rhs, out, floor_, qhead);
         e = hipGetLastError();

@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include <type_traits>
 #include <vector>
 
@@ -19,6 +21,22 @@
 #define PYCLLP_GROWTH_FLOOR 1e3
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, set once per (device, kernel, size): the attribute call costs several
+// microseconds of host time, which a small-batch "repeat solve" caller would pay on every launch
+inline hipError_t set_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<unsigned long long, int> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long key = (unsigned long long)(size_t)fn ^ ((unsigned long long)dev << 56);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done[key] = bytes;
+    return e;
+}
 
 #define WAVE 64
 

@@ -176,8 +176,10 @@ class GeneralLP(StandardLP):
     def to_standard_form(self):
         """The StandardLP  max c'x + f', A' x <= b', x >= 0  with the same optimum (``pycllp/lp.py:725-792``):
         shift x <- x - l, write a <= A x as -A x <= -a, add x <= u - l for the finite upper bounds, and drop every row
-        without a finite bound (``remove_unbounded``, ``pycllp/lp.py:511-529``).  A row, or an upper bound, is kept when it
-        is finite for ANY problem of the batch; a problem for which it is infinite gets the bound +1e30 there."""
+        without a finite bound (``remove_unbounded``, ``pycllp/lp.py:511-529``).  A row, or an upper bound, that is finite
+        for some problems of the batch and infinite for others raises ``ValueError`` exactly as the reference's
+        ``remove_unbounded`` does (``lp.py:518-523``): a stand-in "big" bound would enter the relative tolerances
+        (eps * (1 + |b|)) and the autoscale factors of that LP and ruin its solve."""
         if np.isneginf(self.l).any():
             raise ValueError('Lower bounds (l) contains -inf.')
         m, n, B = self.nrows, self.ncols, self.nproblems
@@ -192,6 +194,11 @@ class GeneralLP(StandardLP):
         keep_lo = np.isfinite(a).any(axis=0)          # rows  -A x <= -a
         keep_hi = np.isfinite(b).any(axis=0)          # rows   A x <=  b
         keep_ub = np.isfinite(u).any(axis=0)          # rows     x <=  u - l
+        for what, bound, keep in (("lower row bound a", a, keep_lo), ("row bound b", b, keep_hi), ("upper bound u", u, keep_ub)):
+            mixed = keep & ~np.isfinite(bound).all(axis=0)
+            if mixed.any():
+                raise ValueError("Can not remove unbounded rows. %s of index %d is unbounded for some problems of the batch "
+                                 "but not all." % (what, int(np.flatnonzero(mixed)[0])))
         rows, cols, data = [], [], []
         rhs = []
         r0 = 0
@@ -205,7 +212,6 @@ class GeneralLP(StandardLP):
         rows.append(r0 + np.arange(ub.size)); cols.append(ub); data.append(np.ones((self.A.data.shape[0], ub.size)))
         rhs.append(u[:, ub])
         bb = np.concatenate(rhs, axis=1)
-        bb = np.where(np.isfinite(bb), bb, 1e30)
         A2 = SparseMatrix(np.concatenate(rows), np.concatenate(cols), np.concatenate(data, axis=1))
         A2._shape = (bb.shape[1], n)
         return StandardLP(A2, bb, c, f)

@@ -88,3 +88,13 @@ def random_sparse_arrays(m, n, nproblems, density=0.025, seed=0):
     b = 0.5 + rs.rand(nproblems, m)
     c = 0.5 + rs.rand(nproblems, n)
     return A, b, c
+
+
+def per_problem_values(A, nproblems, seed=7):
+    """Per-problem values on the structure of the sparse matrix ``A`` (``SparseMatrix.data[nproblems, nnz]``,
+    ``pycllp/lp.py:16-54``): LP k's value of entry e is the shared one times U[0.75, 1.25), drawn row-major from
+    RandomState(seed) -- the first LPs of a batch are the same whatever its size.  Returns (rows, cols, data[B, nnz]) in
+    the coordinate order of ``A.tocoo()``."""
+    Ac = A.tocoo()
+    data = Ac.data[None, :] * (0.75 + 0.5 * np.random.RandomState(seed).rand(nproblems, Ac.nnz))
+    return Ac.row, Ac.col, data

@@ -48,6 +48,31 @@ def unpack(packed, layout, names=("pobj", "dobj", "status", "iters", "y", "x")):
     return out
 
 
+AUTOSCALE_BAND = (0.1, 10.0)
+
+
+def autoscale_wanted(b, c):
+    """The ``autoscale='auto'`` rule: True when, for any LP of the batch, max|b| or max|c| lies outside [0.1, 10] -- the
+    start x = z = y = 1 and the unit floors of the tolerances (eps (1 + |b|)) are tuned to data of order 1 (DESIGN.md section
+    2, scaling caveat: decades away from 1 cost 40-170 iterations and objective accuracy).  numpy arrays or torch tensors."""
+    lo, hi = AUTOSCALE_BAND
+    for v in (b, c):
+        if isinstance(v, torch.Tensor):
+            if v.numel() == 0:
+                continue
+            mx = v.abs().amax(dim=-1)
+            if bool(((mx < lo) | (mx > hi)).any()):
+                return True
+        else:
+            v = np.asarray(v)
+            if v.size == 0:
+                continue
+            mx = np.abs(v).max(axis=-1)
+            if ((mx < lo) | (mx > hi)).any():
+                return True
+    return False
+
+
 def _require_gpu(device):
     if not torch.cuda.is_available():
         raise RuntimeError("pycllp_amd: no ROCm device visible -- the HIP solvers have no CPU fallback")
@@ -59,7 +84,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
     (callers use ``StandardLP.to_equality_form()`` first, as for the OpenCL solver)."""
     name = 'hip_dense_primal_normal'
 
-    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale=False, hsd="auto", warm_start=False,
+    def __init__(self, device=None, stream=None, keep_on_device=False, autoscale="auto", hsd="auto", warm_start=False,
                  **options):
         """``hsd=True`` (PYCLLP_FLAG_HSD) solves on the homogeneous self-dual embedding, the model of the reference's
         CPU solver ``pycllp/ipo/hsd.c``: infeasible (status 2) and unbounded (status 4) LPs are then detected reliably,
@@ -73,13 +98,32 @@ class HipDensePrimalNormalSolver(BaseSolver):
         starts every LP that was optimal there from its previous point (PYCLLP_FLAG_WARM_START); the others, and a first
         solve or one with a different batch size, start from x = z = y = 1.
         ``autoscale=True`` (PYCLLP_FLAG_AUTOSCALE, not in the reference) solves every LP with b/max|b| and c/max|c| and
-        scales the results back: use it when b or c are orders of magnitude away from 1.  Other keyword arguments are
+        scales the results back: for b or c orders of magnitude away from 1.  ``autoscale="auto"`` (default) switches it on
+        in ``solve(lp)`` for a batch in which some LP has max|b| or max|c| outside [0.1, 10] (``autoscale_wanted``) and
+        leaves a batch inside that band -- the reference's test and benchmark regime -- on the reference's arithmetic bit
+        for bit; ``solve_device`` (asynchronous, no look at the data) treats "auto" as off.  Other keyword arguments are
         the fields of ``pycllp_hip_opts`` (eps, delta, r, pivot_floor, refine_tol, max_iter, max_refine, flags)."""
         super(HipDensePrimalNormalSolver, self).__init__()
-        if hsd not in (True, False, "auto"):
+        if isinstance(hsd, str):
+            if hsd != "auto":
+                raise ValueError("hsd must be True, False or 'auto'")
+        elif isinstance(hsd, (bool, np.bool_, int, np.integer)):
+            hsd = bool(hsd)           # 1 / np.bool_(True) mean True (ADVICE r2: `hsd is True` tests below)
+        else:
             raise ValueError("hsd must be True, False or 'auto'")
-        if autoscale:
+        if isinstance(autoscale, str):
+            if autoscale != "auto":
+                raise ValueError("autoscale must be True, False or 'auto'")
+        else:
+            autoscale = bool(autoscale)
+        if int(options.get("flags", 0)) & _native.FLAG_AUTOSCALE:
+            autoscale = True
+        if autoscale is True:
             options["flags"] = int(options.get("flags", 0)) | _native.FLAG_AUTOSCALE
+        elif autoscale == "auto" and int(options.get("flags", 0)) & _native.FLAG_WAVE_KERNEL:
+            autoscale = False
+        self.autoscale = autoscale
+        self._extra_flags = 0        # flags solve(lp) adds for one call (autoscale='auto')
         if hsd is True or (int(options.get("flags", 0)) & _native.FLAG_HSD):
             options["flags"] = int(options.get("flags", 0)) | _native.FLAG_HSD
             hsd = True
@@ -145,7 +189,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
         if type(self) is HipDensePrimalNormalSolver and getattr(lp.A, "nproblems", 1) > 1:
             # per-problem values of A: served by the sparse path's per-problem kernel (one LP per workgroup, values from HBM)
             d = HipSparsePrimalNormalSolver(device=self.device, stream=self.stream, keep_on_device=self.keep_on_device,
-                                            hsd=self.hsd, warm_start=self.warm_start, **self.options)
+                                            autoscale=self.autoscale, hsd=self.hsd, warm_start=self.warm_start, **self.options)
             d.init(lp, verbose=verbose)
             self._delegate, self.m, self.n = d, d.m, d.n
             return
@@ -191,6 +235,8 @@ class HipDensePrimalNormalSolver(BaseSolver):
     def solve_device(self, b, c, warm_start=False, slot=0, **options):
         """Device-resident entry: b [B,m], c [B,n] (torch CUDA or numpy) -> dict of CUDA tensors.
         Asynchronous on the solver's stream."""
+        if getattr(self, "_delegate", None) is not None:
+            return self._delegate.solve_device(b, c, warm_start=warm_start, slot=slot, **options)
         if self._handle is None:
             raise RuntimeError("solve() called before init()")
         b = self._dev(b); c = self._dev(c)
@@ -200,11 +246,12 @@ class HipDensePrimalNormalSolver(BaseSolver):
         B = int(b.shape[0])
         buf = self._buffers(B, slot)
         opts = dict(self.options); opts.update(options)
+        opts["flags"] = int(opts.get("flags", 0)) | self._extra_flags
         if warm_start:
             opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
         o = _native.default_opts(**opts)
-        if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
-            raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
+        if o.max_iter < 1 or o.max_refine < _native.MAX_REFINE_AUTO or not (o.eps > 0):
+            raise ValueError("max_iter must be >= 1, max_refine >= 0 (or -1 = auto) and eps > 0")
         with torch.cuda.device(self.device):
             self._launch(B, b, c, buf, o)
         self._keepalive = (b, c)
@@ -249,11 +296,12 @@ class HipDensePrimalNormalSolver(BaseSolver):
         B = int(b.shape[0])
         st, buf = self._host_staging(B), self._buffers(B, 0)
         opts = dict(self.options)
+        opts["flags"] = int(opts.get("flags", 0)) | self._extra_flags
         if warm:
             opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
         o = _native.default_opts(**opts)
-        if o.max_iter < 1 or o.max_refine < 0 or not (o.eps > 0):
-            raise ValueError("max_iter must be >= 1, max_refine >= 0 and eps > 0")
+        if o.max_iter < 1 or o.max_refine < _native.MAX_REFINE_AUTO or not (o.eps > 0):
+            raise ValueError("max_iter must be >= 1, max_refine >= 0 (or -1 = auto) and eps > 0")
         nchunk = max(1, min(self.PIPELINE_CHUNKS, B // self.PIPELINE_MIN_BATCH))
         edges = [B * k // nchunk for k in range(nchunk + 1)]
         compute = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
@@ -286,10 +334,17 @@ class HipDensePrimalNormalSolver(BaseSolver):
         if not self.warm_start or self._prev_B != B or "set0" not in self.buffers:
             return False
         buf = self.buffers["set0"]
-        bad = buf["status"] != 0
-        if bool(bad.any()):
-            buf["x"][bad] = 1.0; buf["z"][bad] = 1.0; buf["y"][bad] = 0.0 if self.hsd is True else 1.0
+        with self._on_solver_stream():       # the kernel that reads x, z, y is launched on the solver's stream
+            bad = buf["status"] != 0
+            if bool(bad.any()):
+                buf["x"][bad] = 1.0; buf["z"][bad] = 1.0; buf["y"][bad] = 0.0 if self.hsd is True else 1.0
         return True
+
+    def _on_solver_stream(self):
+        """Context in which torch tensor work is queued on the stream the solve kernels run on (gathers and
+        resets issued on torch's current stream raced a kernel launched on a caller-supplied stream)."""
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _resolve_non_optimal(self, b, c, res):
         """hsd='auto': the LPs that did not end optimal are solved again on the homogeneous self-dual embedding and their
@@ -298,27 +353,29 @@ class HipDensePrimalNormalSolver(BaseSolver):
         idx = torch.nonzero(status != 0).flatten() if isinstance(status, torch.Tensor) else np.flatnonzero(status != 0)
         if len(idx) == 0:
             return
-        if isinstance(b, torch.Tensor) or isinstance(c, torch.Tensor):
-            it = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
-            b2, c2 = self._dev(b)[it], self._dev(c)[it]
-        else:
-            hi = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
-            b2, c2 = np.asarray(b)[hi], np.asarray(c)[hi]
         flags = (int(self.options.get("flags", 0)) | _native.FLAG_HSD) & ~_native.FLAG_WARM_START
         full_values = getattr(self, "_a_values", None)
-        if full_values is not None:      # per-problem A values (sparse solver): the rows of the LPs being re-solved
-            it2 = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
-            self._a_values = full_values[it2].contiguous()
-        try:
-            r2 = self.solve_device(b2, c2, slot=3, flags=flags)
-            torch.cuda.synchronize(self.device)
-        finally:
-            if full_values is not None:
-                self._a_values = full_values
-        for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
-            if isinstance(res[k], torch.Tensor):
-                res[k][idx.to(res[k].device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=res[k].device)] = r2[k]
+        with self._on_solver_stream():       # gathers, launch and scatters in ONE stream order
+            if isinstance(b, torch.Tensor) or isinstance(c, torch.Tensor):
+                it = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
+                b2, c2 = self._dev(b)[it], self._dev(c)[it]
             else:
+                hi = idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx
+                b2, c2 = np.asarray(b)[hi], np.asarray(c)[hi]
+            if full_values is not None:      # per-problem A values (sparse solver): the rows of the LPs being re-solved
+                it2 = idx.to(self.device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=self.device)
+                self._a_values = full_values[it2].contiguous()
+            try:
+                r2 = self.solve_device(b2, c2, slot=3, flags=flags)
+            finally:
+                if full_values is not None:
+                    self._a_values = full_values
+            for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
+                if isinstance(res[k], torch.Tensor):
+                    res[k][idx.to(res[k].device) if isinstance(idx, torch.Tensor) else torch.as_tensor(idx, device=res[k].device)] = r2[k]
+            torch.cuda.synchronize(self.device)
+        for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
+            if not isinstance(res[k], torch.Tensor):
                 res[k][idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx] = r2[k].cpu().numpy()
 
     def solve(self, lp, verbose=0):
@@ -337,6 +394,13 @@ class HipDensePrimalNormalSolver(BaseSolver):
             print("Solving %d LPs with %s..." % (lp.nproblems, type(self).__name__))
         f = np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)
         B = int(lp.nproblems)
+        self._extra_flags = _native.FLAG_AUTOSCALE if (self.autoscale == "auto" and autoscale_wanted(lp.b, lp.c)) else 0
+        try:
+            return self._solve_plugin(lp, f, B, verbose)
+        finally:
+            self._extra_flags = 0
+
+    def _solve_plugin(self, lp, f, B, verbose):
         warm = self._prepare_warm(B)
         on_host = not isinstance(lp.b, torch.Tensor) and not isinstance(lp.c, torch.Tensor)
         if on_host and not self.keep_on_device:
@@ -371,6 +435,8 @@ class HipDensePrimalNormalSolver(BaseSolver):
     def newton_step(self, x, z, y, b, c, mu, **options):
         """Stand-alone Newton step dy for B states (the reference's ``solve_primal_normal`` kernel,
         ``pycllp/cl/ldl.cl:602-653``, as launched by its ``tests/test_ldl.py:219-273``)."""
+        if getattr(self, "_delegate", None) is not None:
+            return self._delegate.newton_step(x, z, y, b, c, mu, **options)
         if self._handle is None:
             raise RuntimeError("newton_step() called before init()")
         x, z, y, b, c = [self._dev(np.atleast_2d(v) if not isinstance(v, torch.Tensor) else v) for v in (x, z, y, b, c)]
@@ -388,10 +454,17 @@ class HipDensePrimalNormalSolver(BaseSolver):
         return dy.cpu().numpy()
 
     def launch_info(self):
+        if getattr(self, "_delegate", None) is not None:
+            return self._delegate.launch_info()
         vals = [ctypes.c_int() for _ in range(5)]
         _native.check(_native.lib().pycllp_hip_dense_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
                       "pycllp_hip_dense_launch_info")
-        return dict(zip(("grid", "block", "lds_bytes", "m_pad", "n_pad"), [v.value for v in vals]))
+        d = dict(zip(("grid", "block", "lds_bytes", "m_pad", "n_pad"), [v.value for v in vals]))
+        kind = _native.lib().pycllp_hip_dense_kernel_kind(self._handle)
+        if kind >= 0:      # beyond the lane-group kernels: which of the sparse path's kernels served the last launch
+            d["variant"] = {0: "block", 1: "tables", 2: "dense image"}[kind]
+            d["kernel"] = "wave" if kind else "block"
+        return d
 
 
 class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
@@ -479,6 +552,10 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
         kernel (``pycllp/cl/ldl.cl:656-712``) as launched by its ``tests/test_ldl.py:276-361``."""
         if self._handle is None:
             raise RuntimeError("newton_step() called before init()")
+        if self._a_perm is not None:
+            # the handle holds problem 0's values only: a step for LP k > 0 would silently use the wrong matrix (ADVICE r2)
+            raise NotImplementedError("newton_step() with per-problem values of A: the stand-alone Newton entry takes one "
+                                      "shared matrix (pycllp/cl/ldl.cl:656-712); init a solver per matrix instead")
         x, z, y, b, c = [self._dev(np.atleast_2d(v) if not isinstance(v, torch.Tensor) else v) for v in (x, z, y, b, c)]
         B = int(x.shape[0])
         dy = torch.empty((B, self.m), dtype=torch.float64, device=self.device)

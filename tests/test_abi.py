@@ -30,7 +30,7 @@ def test_defaults_and_argument_errors_without_gpu():
     assert L.pycllp_hip_abi_version() == 1
     o = _native.default_opts()
     assert (o.eps, o.delta, o.r, o.pivot_floor, o.refine_tol) == (1e-10, 0.02, 0.9, 1e-6, 1e-11)
-    assert (o.max_iter, o.max_refine, o.flags) == (200, 5, 0)
+    assert (o.max_iter, o.max_refine, o.flags) == (200, -1, 0)     # -1 = PYCLLP_MAX_REFINE_AUTO: 5 plain / 20 HSD, resolved in C
     assert L.pycllp_hip_dense_max_rows() == 128 and L.pycllp_hip_dense_max_cols() == 512
     h = ctypes.c_void_p()
     # NULL matrix / bad sizes are rejected before any HIP call

@@ -32,8 +32,13 @@ def solve_arrays(A, b, c, **opts):
     return solve_lp(StandardLP(SparseMatrix(matrix=np.asarray(A)), b, c, 0.0), **opts)
 
 
-def oracle_on(elp, **opts):
+def oracle_on(elp, auto=True, **opts):
+    """The oracle on the LP's arrays; mirrors the plugins' default autoscale='auto' (flag 8 when some LP of the batch has
+    max|b| or max|c| outside [0.1, 10]) so that it runs the arithmetic lp.solve(solver) runs."""
     from oracle import port
+    from pycllp_amd.solvers.hip import autoscale_wanted
+    if auto and autoscale_wanted(elp.b, elp.c):
+        opts["flags"] = int(opts.get("flags", 0)) | 8
     return port.dense_solve(elp.A.todense(), elp.b, elp.c, nthreads=8, **opts)
 
 
@@ -377,7 +382,7 @@ def test_all_status_zero_lps_satisfy_the_true_primal_residual():
         b = x0 @ A.T
         c = -rs.rand(B, n) - 0.1
         lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)
-        s = solver_registry["hip_dense_primal_normal"](hsd=False)
+        s = solver_registry["hip_dense_primal_normal"](hsd=False, autoscale=False)    # the reference path's own tolerances
         lp.init(s); lp.solve(s)
         ok = s.status == 0
         assert ok.sum() > B // 2
@@ -455,12 +460,12 @@ def test_repeat_solve_warm_start_through_the_plugin_api(name, m, n):
     assert rel_err(s.primal_obj, full["pobj"]).max() < 1e-8
 
 
-@pytest.mark.parametrize("flags,what", [(2, "first-generation wave-per-LP kernel"), (4, "guarded (cold) LDL' path of the group kernel"),
+@pytest.mark.parametrize("flags,what", [(4, "guarded (cold) LDL' path of the group kernel"),
                                         (16, "generic group kernel although A = [A | I]"), (16 + 4, "generic group kernel, guarded path")])
 @pytest.mark.parametrize("m,n", [(16, 32), (32, 64), (7, 20)])
 def test_alternative_kernel_paths_agree_with_oracle(flags, what, m, n):
-    """PYCLLP_FLAG_WAVE_KERNEL and PYCLLP_FLAG_FORCE_GUARD_PATH select code that the default launch (almost) never
-    runs; both must give the oracle's answers too."""
+    """PYCLLP_FLAG_FORCE_GUARD_PATH and PYCLLP_FLAG_NO_SLACK_PATH select code that the default launch (almost) never
+    runs; it must give the oracle's answers too."""
     A, b, c = problems.random_dense_arrays(m, n, 1024, seed=9)
     elp, s = solve_arrays(A, b, c, flags=flags)
     r = oracle_on(elp)
@@ -562,6 +567,14 @@ def test_hsd_shapes_up_to_the_maximum(m, n):
     opt = s.status == 0
     if opt.any():
         assert rel_err(s.primal_obj[opt], r["pobj"][opt]).max() < 1e-8
+
+
+def test_first_generation_kernel_is_not_in_the_default_build():
+    """the round-1 wave-per-LP kernel is compiled only into diagnostic builds (-DPYCLLP_FIRST_GEN); the
+    shipped library answers its flag with PYCLLP_E_UNSUPPORTED -> NotImplementedError, never with a silent other path."""
+    A, b, c = problems.random_dense_arrays(8, 12, 4, seed=1)
+    with pytest.raises(NotImplementedError):
+        solve_arrays(A, b, c, hsd=False, flags=2)
 
 
 def test_hsd_flag_is_rejected_where_it_is_not_implemented():
@@ -768,12 +781,28 @@ def test_autoscale_on_badly_scaled_lps(kind):
     assert np.abs(s.x @ Ae.T - lp.b).max() < 1e-9 * np.abs(lp.b).max() * 10
     np.testing.assert_allclose(s.x, r["x"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(s.y, r["y"], rtol=1e-5, atol=1e-4)
-    with pytest.raises(ValueError):
-        if kind == "dense":
-            s2 = solver_registry[name](autoscale=True, flags=2)   # not available with the wave kernel
-            lp.init(s2); lp.solve(s2)
-        else:
-            raise ValueError("n/a")
+    # the DEFAULT solver (autoscale='auto') switches the option on for this batch by itself -- same
+    # arithmetic, same results bit for bit -- and leaves a batch inside the band [0.1, 10] alone
+    from pycllp_amd.solvers.hip import autoscale_wanted
+    assert autoscale_wanted(lp.b, lp.c)
+    d = solver_registry[name](hsd=False)
+    lp.init(d)
+    lp.solve(d)
+    s_plain = solver_registry[name](autoscale=True, hsd=False)
+    lp.init(s_plain); lp.solve(s_plain)
+    np.testing.assert_array_equal(d.iters, s_plain.iters)
+    np.testing.assert_array_equal(d.primal_obj, s_plain.primal_obj)
+    np.testing.assert_array_equal(d.x, s_plain.x)
+    off = solver_registry[name](autoscale=False, hsd=False)
+    lp.init(off); lp.solve(off)
+    assert off.iters.mean() > 1.5 * d.iters.mean()            # what the option saves on such a batch
+    b1 = 0.5 + rs.rand(B, m); c1 = 0.5 + rs.rand(B, n)
+    lp1 = StandardLP(SparseMatrix(matrix=A), b1, c1, 0.0).to_equality_form()
+    assert not autoscale_wanted(lp1.b, lp1.c)
+    lp1.init(d); lp1.solve(d)
+    lp1.init(off); lp1.solve(off)
+    np.testing.assert_array_equal(d.primal_obj, off.primal_obj)
+    np.testing.assert_array_equal(d.iters, off.iters)
 
 
 # ---- register-resident wavefront-per-LP kernel of the sparse path (csrc/ipm_wreg.hip) ---------------------------------
@@ -875,6 +904,56 @@ def test_sparse_config5_full_share_properties():
         lp2.solve(s)
         np.testing.assert_array_equal(s.primal_obj, po[perm])
         np.testing.assert_array_equal(s.x, x[perm])
+
+
+def test_hsd_refinement_default_is_resolved_inside_the_library():
+    """a C caller that takes pycllp_hip_default_opts and sets PYCLLP_FLAG_HSD must get the 20-pass
+    refinement cap (the struct carries PYCLLP_MAX_REFINE_AUTO = -1, resolved inside the entry points) -- checked through
+    raw ctypes calls on the 256 LPs of config 5's share around the degenerate LP 7557, which with a cap of 5 sits at a
+    1.6e-10 gap for 58-200 iterations; an explicit 5 is still honoured (more iterations, same optimum)."""
+    import ctypes
+    from pycllp_amd import _native
+    L = _native.lib()
+    A, b, c = problems.random_sparse_arrays(128, 256, 16384, density=0.025, seed=0)
+    lo, hi = 7424, 7680
+    lp = StandardLP(SparseMatrix(matrix=A), b[lo:hi], c[lo:hi], 0.0).to_equality_form()
+    Ae = lp.A.tocsr(); Ae.sort_indices()
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    data, indptr, indices = t(Ae.data, np.float64), t(Ae.indptr, np.int32), t(Ae.indices, np.int32)
+    bd, cd = t(lp.b, np.float64), t(lp.c, np.float64)
+    B, m, n = hi - lo, 128, 384
+    h = ctypes.c_void_p()
+    p = lambda x: ctypes.c_void_p(x.data_ptr())
+    assert L.pycllp_hip_sparse_init(m, n, int(Ae.nnz), p(data), p(indptr), p(indices), None, ctypes.byref(h)) == 0
+    try:
+        out = {}
+        for cap in (-1, 5):
+            o = _native.Opts()
+            L.pycllp_hip_default_opts(ctypes.byref(o))
+            assert o.max_refine == -1
+            o.flags = _native.FLAG_HSD
+            o.max_refine = cap
+            x = torch.empty((B, n), dtype=torch.float64, device=dev); z = torch.empty_like(x)
+            y = torch.empty((B, m), dtype=torch.float64, device=dev)
+            po = torch.empty(B, dtype=torch.float64, device=dev); do = torch.empty_like(po)
+            st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty_like(st)
+            torch.cuda.synchronize()
+            assert L.pycllp_hip_sparse_solve(h, B, p(bd), p(cd), p(x), p(y), p(z), p(po), p(do), p(st), p(it),
+                                             ctypes.byref(o), None) == 0
+            torch.cuda.synchronize()
+            out[cap] = (st.cpu().numpy(), it.cpu().numpy(), po.cpu().numpy())
+        st, it, po = out[-1]
+        assert (st == 0).all() and it.max() <= 60, (it.max(), it.argmax() + lo)
+        ref = oracle_on(lp, flags=32)                      # the oracle's HSD default is the same 20 passes
+        assert (ref["status"] == 0).all() and np.abs(it.astype(int) - ref["iters"]).max() <= 1
+        assert rel_err(po, ref["pobj"]).max() < 1e-9
+        st5, it5, po5 = out[5]
+        assert it5[7557 - lo] > it[7557 - lo]              # the explicit cap is honoured: LP 7557 stalls with it
+        ok = st5 == 0
+        assert rel_err(po5[ok], po[ok]).max() < 1e-8
+    finally:
+        L.pycllp_hip_sparse_free(h)
 
 
 def test_sparse_newton_step_reference_recipe():

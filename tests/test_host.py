@@ -180,6 +180,30 @@ def test_general_lp_to_standard_form_matches_the_reference_fixtures():
         GeneralLP(SparseMatrix(matrix=sp.coo_matrix(np.eye(2))), b=[1.0, 1.0], c=[1.0, 1.0], l=[-np.inf, 0.0], f=0.0).to_standard_form()
 
 
+def test_general_lp_bound_infinite_for_some_problems_only_raises_like_the_reference():
+    """a row / upper bound that is infinite for some problems of the batch and finite for others makes
+    the reference's remove_unbounded raise ValueError (pycllp/lp.py:518-523); a stand-in bound of 1e30 would wreck that LP's
+    tolerances.  A bound that is infinite for EVERY problem is dropped (lp.py:515-517)."""
+    import scipy.sparse as sp
+    from pycllp_amd.lp import GeneralLP
+    rs = np.random.RandomState(5)
+    A = sp.coo_matrix(rs.rand(4, 5))
+    b = 1.0 + rs.rand(3, 4); c = rs.rand(3, 5)
+    bm = b.copy(); bm[2, 1] = np.inf
+    with pytest.raises(ValueError):
+        GeneralLP(SparseMatrix(matrix=A), b=bm, c=c, f=0.0).to_standard_form()
+    um = np.full((3, 5), np.inf); um[0, 2] = 4.0
+    with pytest.raises(ValueError):
+        GeneralLP(SparseMatrix(matrix=A), b=b, c=c, u=um, f=0.0).to_standard_form()
+    am = np.full((3, 4), -np.inf); am[1, 0] = 0.1
+    with pytest.raises(ValueError):
+        GeneralLP(SparseMatrix(matrix=A), b=b, c=c, a=am, f=0.0).to_standard_form()
+    ball = b.copy(); ball[:, 1] = np.inf          # unbounded for every problem: the row goes
+    slp = GeneralLP(SparseMatrix(matrix=A), b=ball, c=c, f=0.0).to_standard_form()
+    assert slp.nrows == 3 and np.isfinite(slp.b).all()
+    np.testing.assert_array_equal(slp.A.todense(), A.toarray()[[0, 2, 3]])
+
+
 def test_per_problem_values_of_A_in_the_containers():
     """SparseMatrix.data[nproblems, nnz] (pycllp/lp.py:16-54): one set of values per problem is accepted (the reference's
     LP classes refuse it, lp.py:335-336), carried through to_equality_form, and a mismatch raises."""

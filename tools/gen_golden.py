@@ -139,6 +139,40 @@ def baseline_sparse(m=128, n=256, density=0.025, nlp=64):
     print("sparse config (%d,%d,%.3f): nnz %d, status" % (m, n, density, A.nnz), np.bincount(g["status"]), "max gap", gap.max())
 
 
+def dense_image_config(m=100, n=80, nlp=64):
+    """A dense StandardLP beyond the lane-group kernels (the shape of the reference's own kernel test is m = 100,
+    tests/test_ldl.py:226-238): SURVEY 8d generator, objectives of the reference solver for the first LPs (inputs are
+    regenerated from the seed; a checksum pins them)."""
+    A, b, c = problems.random_dense_arrays(m, n, nlp, seed=0)
+    g = hsd(A, b, c)
+    np.savez_compressed(os.path.join(OUT, "config_dense_%dx%d.npz" % (m, n)), m=m, n=n, seed=0, nobj=nlp,
+                        input_checksum=np.array([A.sum(), b.sum(), c.sum()]),
+                        pobj=g["pobj"], dobj=g["dobj"], status=g["status"].astype(np.int8), x=g["x"][:8], y=g["y"][:8])
+    gap = np.abs(g["pobj"] - g["dobj"]) / np.maximum(1.0, np.abs(g["pobj"]))
+    print("dense config (%d,%d): %d LPs, status" % (m, n, nlp), np.bincount(g["status"]), "max internal gap", gap.max())
+
+
+def per_problem_a_config(m=128, n=256, density=0.025, nlp=32):
+    """Per-problem values of A on config 5's structure.  The reference's LP classes refuse such a batch
+    (lp.py:335-336) but its CPU solver takes ONE matrix per call: every LP is handed to hsd.c with ITS OWN matrix, which
+    pins the extension to the reference LP by LP.  Inputs come from problems.random_sparse_arrays / per_problem_values
+    (seed 0 / 7); a checksum pins them."""
+    import scipy.sparse as sp
+    A, b, c = problems.random_sparse_arrays(m, n, nlp, density=density, seed=0)
+    rows, cols, data = problems.per_problem_values(A, nlp, seed=7)
+    po, du, st = [], [], []
+    for k in range(nlp):
+        Ak = sp.csr_matrix((data[k], (rows, cols)), shape=(m, n))
+        g = hsd_ref.solve_standard(Ak, b[k:k + 1], c[k:k + 1])
+        po.append(g["pobj"][0]); du.append(g["dobj"][0]); st.append(g["status"][0])
+    po, du = np.array(po), np.array(du)
+    np.savez_compressed(os.path.join(OUT, "config_perA_%dx%d.npz" % (m, n)), m=m, n=n, density=density, seed=0, value_seed=7,
+                        nobj=nlp, input_checksum=np.array([data.sum(), b.sum(), c.sum()]),
+                        pobj=po, dobj=du, status=np.array(st, dtype=np.int8))
+    print("per-problem-A config (%d,%d): %d LPs, status" % (m, n, nlp), np.bincount(st),
+          "max gap", (np.abs(po - du) / np.maximum(1.0, np.abs(po))).max())
+
+
 def status_cases(nshape=8, nlp=32):
     """Mixed-sign random LPs, most of them infeasible or unbounded: inputs, the status the reference's HSD solver
     reports (ipo/hsd.c:156-177: 0 optimal, 2 primal infeasible, 4 dual infeasible) and, as an independent arbiter,
@@ -169,6 +203,10 @@ if __name__ == "__main__":
     if not hsd_ref.available():
         sys.exit("oracle/_ref/libhsd_ref.so missing: run `make -C oracle` in the container that has /root/reference")
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:          # only the named fixtures, e.g. `gen_golden.py dense_image_config per_problem_a_config`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     textbook()
     small_problem()
     random_helpers()
@@ -176,4 +214,6 @@ if __name__ == "__main__":
     baseline_config(16, 32)
     baseline_config(32, 64)
     baseline_sparse()
+    dense_image_config()
+    per_problem_a_config()
     status_cases()
