@@ -767,6 +767,11 @@ struct pycllp_hip_sparse {
     int lds_with_a = 0;     // LDS bytes with A's arrays in LDS (what per-problem values need), 0 when that does not fit
     int last_wreg = 0;      // 1 when the last solve ran on the wave kernel
     WregPlan* wreg = nullptr;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
+    WregPlan* wreg_pa = nullptr;  // its per-problem-A plan (structure tables only), built by the first pycllp_hip_sparse_solve_batch
+    WregPlan* last_plan = nullptr;
+    bool wreg_pa_tried = false;
+    int max_lds = 0;
+    std::vector<double> host_val; std::vector<int> host_ptr, host_col;   // host CSR copy (what a PA plan is built from)
 };
 
 template <typename T>
@@ -1090,13 +1095,15 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     // the register-resident one-LP-per-wavefront kernel takes over whenever its tables fit (ipm_wreg.hip)
     {
         WregPlan* wp = nullptr;
-        const int rc = wreg_plan_create(m, n, nnz, val.data(), ptr.data(), col.data(), max_lds, st, &wp);
+        const int rc = wreg_plan_create(m, n, nnz, val.data(), ptr.data(), col.data(), max_lds, 0, st, &wp);
         if (rc >= 1000) {
             (void)hipFree(h->dev_blob); h->ring.destroy(); delete h;
             return set_err(rc - 1000, "wreg_plan_create");
         }
         h->wreg = (rc == 0) ? wp : nullptr;
     }
+    h->max_lds = max_lds;
+    h->host_val = val; h->host_ptr = ptr; h->host_col = col;
     *handle = h;
     return 0;
 }
@@ -1118,16 +1125,27 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     BlockA desc = h->desc;
     int lds = h->lds;
     if (a_batch) { desc.a_in_lds = 1; lds = h->lds_with_a; }
-    // (autoscale exists in the plain wave kernel; with HSD it runs on the block kernel)
-    const bool use_wreg = !a_batch && h->wreg && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL) &&
-                          !((o.flags & PYCLLP_FLAG_AUTOSCALE) && (o.flags & PYCLLP_FLAG_HSD));
+    // per-problem values: the PA plan of the wave kernel (structure tables; built on first use), else the shared-A plan
+    if (a_batch && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL)) {
+        std::lock_guard<std::mutex> g(h->info_mu);
+        if (!h->wreg_pa_tried) {
+            h->wreg_pa_tried = true;
+            WregPlan* wp = nullptr;
+            const int rc = wreg_plan_create(h->desc.m, h->desc.n, h->desc.nnz, h->host_val.data(), h->host_ptr.data(), h->host_col.data(),
+                                            h->max_lds, 1, st, &wp);
+            if (rc >= 1000) return set_err(rc - 1000, "wreg_plan_create (per-problem A)");
+            h->wreg_pa = (rc == 0) ? wp : nullptr;
+        }
+    }
+    WregPlan* wplan = a_batch ? h->wreg_pa : h->wreg;
+    const bool use_wreg = wplan && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL);
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
         HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));
         int* qw = nullptr; unsigned sw = 0;
         hipError_t ew = h->ring.acquire(st, &qw, &sw);
         if (ew == hipSuccess) {
-            ew = wreg_launch_solve(h->wreg, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qw,
+            ew = wreg_launch_solve(wplan, B, a_batch, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qw,
                                    worklist, o, h->num_cu, st, &grid_w);
             hipError_t er = h->ring.release(sw, st);
             if (ew == hipSuccess) ew = er;
@@ -1152,6 +1170,7 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     {
         std::lock_guard<std::mutex> g(h->info_mu);
         h->last_wreg = use_wreg ? 1 : 0;
+        h->last_plan = use_wreg ? wplan : nullptr;
         h->grid = use_wreg ? grid_w : (int)blocks;
     }
     if (e != hipSuccess) return set_err((int)e, "ipm_block_kernel launch");
@@ -1208,9 +1227,9 @@ int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse* h, int* grid, int* bl
     if (!h) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_launch_info: bad argument");
     std::lock_guard<std::mutex> g(h->info_mu);
     if (grid) *grid = h->grid;
-    if (block) *block = h->last_wreg ? wreg_block_threads(h->wreg) : BLK_T;
-    if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->wreg) : h->lds;
-    if (kernel) *kernel = h->last_wreg ? wreg_variant(h->wreg) : 0;
+    if (block) *block = h->last_wreg ? wreg_block_threads(h->last_plan) : BLK_T;
+    if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->last_plan) : h->lds;
+    if (kernel) *kernel = h->last_wreg ? wreg_variant(h->last_plan) : 0;
     return 0;
 }
 
@@ -1268,6 +1287,7 @@ void pycllp_hip_sparse_free(pycllp_hip_sparse* h) {
     if (h->dev_blob) (void)hipFree(h->dev_blob);
     h->ring.destroy();
     wreg_plan_free(h->wreg);
+    wreg_plan_free(h->wreg_pa);
     delete h;
 }
 

@@ -261,9 +261,56 @@ __device__ __forceinline__ void lds_terms3(unsigned aw, unsigned ac, double (&w)
                  : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]) : "v"(aw), "v"(ac) : "memory");
 }
 
+// ---- per-problem values of A (PA variants): one more level of indirection, same batching ---------------------------
+// eight ELL slots of the structure tables: s[k] = *(unsigned short*)(as + 128 k) (CSR index of the slot's value),
+// r[k] = *(unsigned short*)(ar + 128 k) (its row)
+__device__ __forceinline__ void lds_ell8_uu(unsigned as, unsigned ar, unsigned (&s)[8], unsigned (&r)[8]) {
+    asm volatile("ds_read_u16 %0, %16\n\tds_read_u16 %1, %16 offset:128\n\tds_read_u16 %2, %16 offset:256\n\tds_read_u16 %3, %16 offset:384\n\t"
+                 "ds_read_u16 %4, %16 offset:512\n\tds_read_u16 %5, %16 offset:640\n\tds_read_u16 %6, %16 offset:768\n\tds_read_u16 %7, %16 offset:896\n\t"
+                 "ds_read_u16 %8, %17\n\tds_read_u16 %9, %17 offset:128\n\tds_read_u16 %10, %17 offset:256\n\tds_read_u16 %11, %17 offset:384\n\t"
+                 "ds_read_u16 %12, %17 offset:512\n\tds_read_u16 %13, %17 offset:640\n\tds_read_u16 %14, %17 offset:768\n\tds_read_u16 %15, %17 offset:896\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(s[4]), "=&v"(s[5]), "=&v"(s[6]), "=&v"(s[7]),
+                   "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(as), "v"(ar) : "memory");
+}
+// twelve gathers, one wait: o[k] = *(double*)a[k]
+__device__ __forceinline__ void lds_gather12(const unsigned (&a)[12], double (&o)[12]) {
+    asm volatile("ds_read_b64 %0, %12\n\tds_read_b64 %1, %13\n\tds_read_b64 %2, %14\n\tds_read_b64 %3, %15\n\t"
+                 "ds_read_b64 %4, %16\n\tds_read_b64 %5, %17\n\tds_read_b64 %6, %18\n\tds_read_b64 %7, %19\n\t"
+                 "ds_read_b64 %8, %20\n\tds_read_b64 %9, %21\n\tds_read_b64 %10, %22\n\tds_read_b64 %11, %23\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                   "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]) : "memory");
+}
+__device__ __forceinline__ void lds_gather10(const unsigned (&a)[10], double (&o)[10]) {
+    asm volatile("ds_read_b64 %0, %10\n\tds_read_b64 %1, %11\n\tds_read_b64 %2, %12\n\tds_read_b64 %3, %13\n\t"
+                 "ds_read_b64 %4, %14\n\tds_read_b64 %5, %15\n\tds_read_b64 %6, %16\n\tds_read_b64 %7, %17\n\t"
+                 "ds_read_b64 %8, %18\n\tds_read_b64 %9, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                   "=&v"(o[8]), "=&v"(o[9])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+                   "v"(a[8]), "v"(a[9]) : "memory");
+}
+// term records of the structure tables: c[k] = *(unsigned*)a[k], d[k] = *(unsigned*)b[k], k < 4
+__device__ __forceinline__ void lds_gather4_u_u(const unsigned (&a)[4], const unsigned (&b)[4], unsigned (&c)[4], unsigned (&d)[4]) {
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+                 "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]) : "memory");
+}
+// three consecutive records of two u32 tables: c[k] = ((unsigned*)aa)[k], d[k] = ((unsigned*)ab)[k]
+__device__ __forceinline__ void lds_terms3_uu(unsigned aa, unsigned ab, unsigned (&c)[3], unsigned (&d)[3]) {
+    asm volatile("ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:8\n\t"
+                 "ds_read_b32 %3, %7\n\tds_read_b32 %4, %7 offset:4\n\tds_read_b32 %5, %7 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]) : "v"(aa), "v"(ab) : "memory");
+}
+
 // ---- the per-wave machinery ------------------------------------------------------------------------------------
-template <int MB, int NQ, bool DA = false>
+template <int MB, int NQ, bool DA = false, bool PA = false>
 struct WReg {
+    static_assert(!(DA && PA), "per-problem values exist on the table variants only");
     using G = WGeo<MB>;
     static constexpr int MP = G::MP, MR = G::MR, MPL = G::MPL, NP = 64 * NQ, STAGE_D = stage_d(NQ), TILE_OFF = tile_off(NQ);
 
@@ -277,6 +324,8 @@ struct WReg {
     const double* ec_val; const unsigned short* ec_row; const unsigned* colmap;
     const double* t_w; const unsigned* t_cd; const int* lev;
     const int* meta;
+    // PA: structure-only tables (see WregTab); csr_val then points at THIS WAVE's copy of its LP's values, cvl_()
+    const unsigned short* ec_src; const unsigned* t_ab;
     // DA: the dense image (LDS), its row stride and the number of dense columns; n_sl = n - nd identity columns behind them
     const double* img; int nd, AS, imgR;
     // LDS: this wave's area, every array at a COMPILE-TIME offset from the one base pointer W0 -- so that the address
@@ -291,6 +340,7 @@ struct WReg {
     __device__ __forceinline__ double* um_() const { return W0 + STAGE_D + MB * WL + NP + 2 * MP; }       // [MP] solve vector in/out
     __device__ __forceinline__ double* rdv_() const { return W0 + STAGE_D + MB * WL + NP + 3 * MP; }      // [MP] 1/D
     __device__ __forceinline__ double* flr_() const { return W0 + STAGE_D + MB * WL + NP + 4 * MP; }      // [MP] per-column pivot floors (HSD)
+    __device__ __forceinline__ double* cvl_() const { return W0 + G::WAVE_D(NQ); }                         // PA: [nnzp] this LP's values of A, CSR order
     mutable int lane, q, c16;
     int m, n, rmax;
     // Every lane-dependent LDS address in this kernel is `lane`, `q` or `c16` times something plus a constant.  Left alone the
@@ -331,6 +381,31 @@ struct WReg {
                 const bool sl = p >= nd && p < n;
                 const double us = u[sl ? p - nd : 0];
                 out[qq] = (p < nd) ? a0 + a1 : (sl ? us : 0.0);
+            }
+            return;
+        }
+        if constexpr (PA) {
+            // the slot's value through its CSR index into this wave's copy of the LP's values: one more gather per round
+            const unsigned ub = lds_addr(u), sb = lds_addr(ec_src) + 2 * lane, rb = lds_addr(ec_row) + 2 * lane, cvb = lds_addr(csr_val);
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) {
+                const int cm = __builtin_amdgcn_readfirstlane(meta[qq]);
+                const int cof = __builtin_amdgcn_readfirstlane(meta[META_COFF + qq]);
+                double a0 = 0.0, a1 = 0.0;
+                for (int t0 = 0; t0 < cm; t0 += 8) {
+                    double av[8], uv[8]; unsigned sr[8], rw[8], va[8], ua[8];
+                    lds_ell8_uu(sb + 128 * (cof + t0), rb + 128 * (cof + t0), sr, rw);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { va[k] = cvb + 8 * sr[k]; ua[k] = ub + 8 * ((t0 + k < cm) ? rw[k] : 0u); }
+                    lds_gather8(va, av);
+                    lds_gather8(ua, uv);
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        a0 = fma((t0 + k < cm) ? av[k] : 0.0, uv[k], a0);
+                        a1 = fma((t0 + k + 1 < cm) ? av[k + 1] : 0.0, uv[k + 1], a1);
+                    }
+                }
+                out[qq] = a0 + a1;
             }
             return;
         }
@@ -468,15 +543,57 @@ struct WReg {
             if (on) dstbuf[cd[0] >> 16] = acc;
         }
     }
+    // PA forms of the two passes: the weight of a term is the product of the two entries of A that t_ab names, taken
+    // from this wave's copy of its LP's values (padded records name the zero entry behind the values)
+    __device__ __forceinline__ void scatter_first_pa(double* dstbuf, int i0, int i1) const {
+        const unsigned abb = lds_addr(t_ab), cb = lds_addr(t_cd), db = lds_addr(vd_()), cvb = lds_addr(csr_val);
+        for (int base = i0; base < i1; base += 256) {
+            unsigned aa[4], ac[4], ab[4], cd[4], ga[12]; bool on[4]; double gv[12];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ik = base + lane + 64 * k;
+                on[k] = ik < i1;
+                const int ic = on[k] ? ik : i0;
+                aa[k] = abb + 4 * ic; ac[k] = cb + 4 * ic;
+            }
+            lds_gather4_u_u(aa, ac, ab, cd);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ga[3 * k] = cvb + 8 * (ab[k] & 0xffffu); ga[3 * k + 1] = cvb + 8 * (ab[k] >> 16); ga[3 * k + 2] = db + 8 * (cd[k] & 0xffffu);
+            }
+            lds_gather12(ga, gv);
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (on[k]) dstbuf[cd[k] >> 16] = (gv[3 * k] * gv[3 * k + 1]) * gv[3 * k + 2];
+        }
+    }
+    __device__ __forceinline__ void scatter_more_pa(double* dstbuf, int i0, int i1) const {
+        const unsigned abb = lds_addr(t_ab), cb = lds_addr(t_cd), db = lds_addr(vd_()), ob = lds_addr(dstbuf), cvb = lds_addr(csr_val);
+        for (int base = i0; base < i1; base += 192) {
+            const int ik = base + 3 * lane;
+            const bool on = ik < i1;
+            const int ic = on ? ik : i0;
+            unsigned ab[3], cd[3], ga[10]; double gv[10];
+            lds_terms3_uu(abb + 4 * ic, cb + 4 * ic, ab, cd);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                ga[3 * k] = cvb + 8 * (ab[k] & 0xffffu); ga[3 * k + 1] = cvb + 8 * (ab[k] >> 16); ga[3 * k + 2] = db + 8 * (cd[k] & 0xffffu);
+            }
+            ga[9] = ob + 8 * (cd[0] >> 16);
+            lds_gather10(ga, gv);
+            const double acc = fma(gv[6] * gv[7], gv[8], fma(gv[3] * gv[4], gv[5], fma(gv[0] * gv[1], gv[2], gv[9])));
+            if (on) dstbuf[cd[0] >> 16] = acc;
+        }
+    }
     // all terms of Gram group g into dstbuf (zeroed by the caller: entries the structure does not have stay 0)
     __device__ __forceinline__ void scatter_group(double* dstbuf, int g) const {
         const int l0 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g]), l1 = __builtin_amdgcn_readfirstlane(meta[META_SEG + g + 1]);
         if (l0 < l1) {
             int i0 = __builtin_amdgcn_readfirstlane(lev[l0]), i1 = __builtin_amdgcn_readfirstlane(lev[l0 + 1]);
-            if (i1 - i0 > 256) scatter_first<6>(dstbuf, i0, i1); else scatter_first<4>(dstbuf, i0, i1);
+            if constexpr (PA) scatter_first_pa(dstbuf, i0, i1);
+            else { if (i1 - i0 > 256) scatter_first<6>(dstbuf, i0, i1); else scatter_first<4>(dstbuf, i0, i1); }
             for (int l = l0 + 1; l < l1; l++) {
                 i0 = i1; i1 = __builtin_amdgcn_readfirstlane(lev[l + 1]);
-                scatter_more(dstbuf, i0, i1);
+                if constexpr (PA) scatter_more_pa(dstbuf, i0, i1); else scatter_more(dstbuf, i0, i1);
             }
         }
     }
@@ -859,16 +976,44 @@ struct WReg {
     }
 };
 
-template <int MB, int NQ, bool DA>
-__device__ __forceinline__ void wreg_carve(WReg<MB, NQ, DA>& w, double* W0, int tid) {
-    using G = WGeo<MB>;
+template <int MB, int NQ, bool DA, bool PA>
+__device__ __forceinline__ void wreg_carve(WReg<MB, NQ, DA, PA>& w, double* W0, int tid) {
     w.W0 = W0;
     w.lane = tid & 63; w.q = w.lane >> 4; w.c16 = w.lane & 15;
 }
 
-template <int MB, int NQ, bool DA>
-__device__ __forceinline__ void wreg_setup(WReg<MB, NQ, DA>& w, const WregTab& T, unsigned char* lraw, int tid) {
+template <int MB, int NQ, bool DA, bool PA>
+__device__ __forceinline__ void wreg_setup(WReg<MB, NQ, DA, PA>& w, const WregTab& T, unsigned char* lraw, int tid) {
     using G = WGeo<MB>;
+    if constexpr (PA) {
+        // structure tables only; the values of a wave's LP go behind its wave area when it takes the LP
+        int* s_lev = (int*)(lraw + T.o_lev);
+        int* s_meta = (int*)(lraw + T.o_meta);
+        unsigned short* s_csr_col = (unsigned short*)(lraw + T.o_csr_col);
+        unsigned short* s_csr_ptr = (unsigned short*)(lraw + T.o_csr_ptr);
+        unsigned short* s_csr_len = (unsigned short*)(lraw + T.o_csr_len);
+        unsigned short* s_ec_row = (unsigned short*)(lraw + T.o_ec_row);
+        unsigned short* s_ec_src = (unsigned short*)(lraw + T.o_ec_src);
+        unsigned* s_colmap = (unsigned*)(lraw + T.o_colmap);
+        unsigned* s_t_cd = (unsigned*)(lraw + T.o_t_cd);
+        unsigned* s_t_ab = (unsigned*)(lraw + T.o_t_ab);
+        const int nth = blockDim.x;
+        for (int i = tid; i < T.nnz; i += nth) s_csr_col[i] = T.csr_col[i];
+        for (int i = tid; i < G::MPL; i += nth) { s_csr_ptr[i] = T.csr_ptr[i]; s_csr_len[i] = T.csr_len[i]; }
+        for (int i = tid; i < T.ctot * 64; i += nth) { s_ec_row[i] = T.ec_row[i]; s_ec_src[i] = T.ec_src[i]; }
+        for (int i = tid; i < 64 * NQ; i += nth) s_colmap[i] = T.colmap[i];
+        for (int i = tid; i < T.n_term; i += nth) { s_t_cd[i] = T.t_cd[i]; s_t_ab[i] = T.t_ab[i]; }
+        for (int i = tid; i <= T.n_lev; i += nth) s_lev[i] = T.lev[i];
+        for (int i = tid; i < META_N; i += nth) s_meta[i] = T.meta[i];
+        wreg_carve(w, (double*)(lraw + T.o_wave) + (size_t)(tid >> 6) * T.wave_doubles, tid);
+        for (int i = T.nnz + (tid & 63); i < T.nnzp; i += 64) w.cvl_()[i] = 0.0;       // the zero entry padded records name
+        __syncthreads();
+        w.csr_val = w.cvl_(); w.csr_col = s_csr_col; w.csr_ptr = s_csr_ptr; w.csr_len = s_csr_len;
+        w.ec_val = nullptr; w.ec_row = s_ec_row; w.ec_src = s_ec_src; w.colmap = s_colmap;
+        w.t_w = nullptr; w.t_cd = s_t_cd; w.t_ab = s_t_ab; w.lev = s_lev; w.meta = s_meta;
+        w.m = T.m; w.n = T.n; w.rmax = T.rmax;
+        return;
+    }
     if constexpr (DA) {
         double* s_img = (double*)(lraw + T.o_img);
         const int cnt = T.img_rows * T.as;
@@ -916,8 +1061,8 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ, DA>& w, const WregTab& T
 // TCV: the caller has parked x and z in the stage (at NP, 2 NP) and cv = c - A'y in vd_() in place of d; t = cv + mu / x and
 // d = x / z are formed here (the same expressions the caller used for the right-hand side).
 // Out: dy (per row), dx, wv = A'dy, e = rho - A dx.  Returns the refinement passes used; `bad` reports a non-finite dy.
-template <bool TCV, int MB, int NQ, bool DA>
-__device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
+template <bool TCV, int MB, int NQ, bool DA, bool PA>
+__device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA, PA>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
                                             const double (&rho)[WGeo<MB>::MR], double etol, int max_refine, double mu,
                                             double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ],
                                             double (&e)[WGeo<MB>::MR], bool& bad STAMP_ARGS) {
@@ -984,19 +1129,36 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA>& w, const bool (&ok
     return pass;
 }
 
+// PA: the values of LP `lp` (a row of a_batch [B, nnz], CSR order of the plan) into this wave's copy -- HBM -> LDS once per
+// LP, 8 nnz bytes next to the 16 (m + n) + 24 of b, c, x, y; through a buffer descriptor (see row_rsrc), all loads of the
+// wave in flight before the first store
+template <int MB, int NQ, bool DA, bool PA>
+__device__ __forceinline__ void load_lp_values(WReg<MB, NQ, DA, PA>& w, const double* ag, long lp, int nnz) {
+    const __amdgpu_buffer_rsrc_t ra = row_rsrc(ag + lp * nnz, nnz);
+    double* cv = w.cvl_();
+    for (int e0 = 0; e0 < nnz; e0 += 512) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = buf_ld(ra, 8u * (unsigned)(e0 + 64 * k + w.lane));      // past the row: 0
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (e0 + 64 * k + w.lane < nnz) cv[e0 + 64 * k + w.lane] = v[k];
+    }
+    wave_lds_sync();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // solve kernel: sparse_standard_primal_normal (primal_normal.cl:287-375), one LP per wavefront
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ, bool DA>
+template <int MB, int NQ, bool DA, bool PA>
 __global__ void __launch_bounds__(256, 1)
-ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg,
+ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* __restrict__ bg, const double* __restrict__ cg,
                 double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
                 double* __restrict__ dobj, int* __restrict__ status, int* __restrict__ iters, int* __restrict__ queue,
                 int* __restrict__ defer, DevOpts o) {
     using G = WGeo<MB>;
     constexpr int MR = G::MR, MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
-    WReg<MB, NQ, DA> w;
+    WReg<MB, NQ, DA, PA> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int& lane = w.lane;
@@ -1019,6 +1181,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     }
     STAMP_DECL
     while (lp < B) {
+        if constexpr (PA) load_lp_values(w, ag, lp, T.nnz);
         double x[NQ], z[NQ];
         double c2 = 0.0;
         const __amdgpu_buffer_rsrc_t rc = row_rsrc(cg + lp * n, n), rx = row_rsrc(xg + lp * n, n), rz = row_rsrc(zg ? zg + lp * n : nullptr, n);
@@ -1266,21 +1429,22 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 // branch, csrc/ipm_group_hsd.inc): tau and kappa are wave-uniform scalars, one factorisation serves the two right-hand
 // sides  M p = A(d c) - b  and  M q = A(d r1) - eta rho, the pivot floor of column j is pivot_floor^2 |M_jj|
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ, bool DA>
+template <int MB, int NQ, bool DA, bool PA>
 __global__ void __launch_bounds__(256, 1)
-hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg,
+hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* __restrict__ bg, const double* __restrict__ cg,
                 double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
                 double* __restrict__ dobj, int* __restrict__ status, int* __restrict__ iters, int* __restrict__ queue,
                 int* __restrict__ defer, DevOpts o) {
     using G = WGeo<MB>;
     constexpr int MR = G::MR, MP = G::MP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lraw[];
-    WReg<MB, NQ, DA> w;
+    WReg<MB, NQ, DA, PA> w;
     USE_AGPR_FORM();
     wreg_setup(w, T, lraw, threadIdx.x);
     const int& lane = w.lane;
     const int m = w.m, n = w.n;
     const bool warm = (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+    const bool autoscale = (o.flags & PYCLLP_FLAG_AUTOSCALE) != 0;
     const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
     double* vx = w.stage_();
     double* pv = w.flr_();          // p = M^-1 (A(d c) - b): the floor vector is dead once the factor exists
@@ -1298,27 +1462,45 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
     }
     STAMP_DECL
     while (lp < B) {
+        if constexpr (PA) load_lp_values(w, ag, lp, T.nnz);
         double x[NQ], z[NQ];
         double c2 = 0.0, g0 = 0.0;
         const __amdgpu_buffer_rsrc_t rc = row_rsrc(cg + lp * n, n), rx = row_rsrc(xg + lp * n, n), rz = row_rsrc(zg ? zg + lp * n : nullptr, n);
+        // PYCLLP_FLAG_AUTOSCALE: as in ipm_wreg_kernel -- the LP is solved with b / max|b| and c / max|c| (the same divisions as
+        // ipm_block_kernel and the oracle), undone when storing
+        double sb = 1.0, sc = 1.0;
+        if (autoscale) {
+            double cm = 0.0, bm = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < NQ; qq++) cm = fmax(cm, fabs(buf_ld(rc, w.coff(qq))));
+#pragma unroll
+            for (int r2 = 0; r2 < MR; r2++) bm = fmax(bm, okr[r2] ? fabs(bg[lp * m + lane + 64 * r2]) : 0.0);
+            sb = wmax(bm); sc = wmax(cm);
+            sb = uni((sb > 0.0) ? sb : 1.0); sc = uni((sc > 0.0) ? sc : 1.0);
+        }
 #pragma unroll
         for (int qq = 0; qq < NQ; qq++) {
             const unsigned jo = w.coff(qq);
-            const double cj = buf_ld(rc, jo);
+            double cj = buf_ld(rc, jo);
+            if (autoscale) cj = cj / sc;
             c2 = fma(cj, cj, c2);
             x[qq] = (warm && okc[qq]) ? buf_ld(rx, jo) : 1.0;
             z[qq] = (warm && okc[qq]) ? buf_ld(rz, jo) : 1.0;
+            if (autoscale && warm) { x[qq] = x[qq] / sb; z[qq] = z[qq] / sc; }
             g0 += okc[qq] ? x[qq] * z[qq] : 0.0;
         }
         double b2 = 0.0;
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) {
             const int i = lane + 64 * r2;
-            const double bi = okr[r2] ? bg[lp * m + i] : 0.0;
+            double bi = okr[r2] ? bg[lp * m + i] : 0.0;
+            if (autoscale) bi = bi / sb;
             b2 = fma(bi, bi, b2);
             if (i < MP) {
+                double yi = (okr[r2] && warm && yg) ? yg[lp * m + i] : 0.0;
+                if (autoscale && warm && yg) yi = yi / sc;
                 w.bs_()[i] = bi;
-                w.ys_()[i] = (okr[r2] && warm && yg) ? yg[lp * m + i] : 0.0;
+                w.ys_()[i] = yi;
             }
         }
         wave_lds_sync();
@@ -1350,6 +1532,10 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) cq[qq] = buf_ld(rc, w.coff(qq));   // in flight (vmcnt) while A'y runs on LDS; 0 in the padded positions
             w.At(w.ys_(), v);
+            if (autoscale) {
+#pragma unroll
+                for (int qq = 0; qq < NQ; qq++) cq[qq] = cq[qq] / sc;
+            }
             double s2 = 0.0, gam = 0.0, pp = 0.0;
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
@@ -1456,6 +1642,10 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
                         STAMP(7)
                         double w2[NQ], d[NQ];
                         w.At(w.um_(), w2);
+                        if (autoscale && pass < 2) {
+#pragma unroll
+                            for (int qq = 0; qq < NQ; qq++) c2q[qq] = c2q[qq] / sc;
+                        }
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++)
                             d[qq] = okc[qq] ? w.stage_()[64 * NQ + lane + 64 * qq] * fast_rcp(w.stage_()[128 * NQ + lane + 64 * qq]) : 0.0;
@@ -1577,16 +1767,16 @@ hsd_wreg_kernel(WregTab T, long B, const double* __restrict__ bg, const double* 
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {      // (padded positions, null z: dropped)
                 const unsigned jo = w.coff(qq);
-                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq] * rt); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq] * rt);
+                buf_st(rx, jo, w.stage_()[64 * NQ + lane + 64 * qq] * rt * sb); buf_st(rz, jo, w.stage_()[128 * NQ + lane + 64 * qq] * rt * sc);
             }
 #pragma unroll
             for (int r2 = 0; r2 < MR; r2++) {
                 const int i = lane + 64 * r2;
-                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i] * rt;
+                if (yg && okr[r2]) yg[lp * m + i] = w.ys_()[i] * rt * sc;
             }
             if (lane == 0) {
-                if (pobj) pobj[lp] = po * rt;
-                if (dobj) dobj[lp] = du * rt;
+                if (pobj) pobj[lp] = po * rt * (sb * sc);
+                if (dobj) dobj[lp] = du * rt * (sb * sc);
                 status[lp] = stat;
                 if (iters) iters[lp] = it;
             }
@@ -1780,7 +1970,7 @@ __global__ void wreg_selftest_kernel(double* out) {
 struct WregPlan {
     WregTab tab;
     int mb, nq;
-    bool da = false;
+    bool da = false, pa = false;
     void* dev_blob;
 };
 
@@ -1794,23 +1984,23 @@ size_t put(std::vector<char>& host, const std::vector<T>& v) {
     return off;
 }
 
-template <int MB, int NQ, bool DA>
-hipError_t do_solve(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
+template <int MB, int NQ, bool DA, bool PA>
+hipError_t do_solve(const WregTab& T, long B, const double* a, const double* b, const double* c, double* x, double* y, double* z,
                     double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                     hipStream_t st) {
-    hipError_t e = set_dyn_lds((const void*)ipm_wreg_kernel<MB, NQ, DA>, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)ipm_wreg_kernel<MB, NQ, DA, PA>, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA, PA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, a, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
     return hipGetLastError();
 }
-template <int MB, int NQ, bool DA>
-hipError_t do_solve_hsd(const WregTab& T, long B, const double* b, const double* c, double* x, double* y, double* z,
+template <int MB, int NQ, bool DA, bool PA>
+hipError_t do_solve_hsd(const WregTab& T, long B, const double* a, const double* b, const double* c, double* x, double* y, double* z,
                         double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                         hipStream_t st) {
-    hipError_t e = set_dyn_lds((const void*)hsd_wreg_kernel<MB, NQ, DA>, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)hsd_wreg_kernel<MB, NQ, DA, PA>, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ, DA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL((hsd_wreg_kernel<MB, NQ, DA, PA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, a, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
     return hipGetLastError();
 }
@@ -1824,14 +2014,20 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
     return hipGetLastError();
 }
 
-#define WVARIANT(MB, NQ, DA) { MB, NQ, DA, do_solve<MB, NQ, DA>, do_solve_hsd<MB, NQ, DA>, do_newton<MB, NQ, DA> }
+#define WVARIANT(MB, NQ, DA) { MB, NQ, DA, false, do_solve<MB, NQ, DA, false>, do_solve_hsd<MB, NQ, DA, false>, do_newton<MB, NQ, DA> }
+#define WVARIANT_PA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true>, do_solve_hsd<MB, NQ, false, true>, nullptr }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
 const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
                                    WVARIANT(7, 6, false), WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false) };
 const int kNumWVariantsTab = sizeof(kWVariantsTab) / sizeof(kWVariantsTab[0]);
-const int kNumWVariants = kNumWVariantsTab + kNumWVariantsDA;
-struct VariantList { const WVariant& operator[](int i) const { return i < kNumWVariantsTab ? kWVariantsTab[i] : kWVariantsDA[i - kNumWVariantsTab]; } };
+const int kNumWVariants = kNumWVariantsTab + kNumWVariantsDA + kNumWVariantsPA;
+struct VariantList {
+    const WVariant& operator[](int i) const {
+        return i < kNumWVariantsTab ? kWVariantsTab[i]
+             : (i < kNumWVariantsTab + kNumWVariantsDA ? kWVariantsDA[i - kNumWVariantsTab] : kWVariantsPA[i - kNumWVariantsTab - kNumWVariantsDA]);
+    }
+};
 const VariantList kWVariants{};
 #endif
 
@@ -1850,6 +2046,17 @@ extern const WVariant kWVariantsDA[] = WVARIANTS_DA;
 extern const int kNumWVariantsDA = sizeof(kWVariantsDA) / sizeof(kWVariantsDA[0]);
 #endif
 #endif
+#if WREG_PART == 2
+// per-problem values of A: every (MB, NQ) of the table variants, solve + HSD kernels (third translation unit)
+#define WVARIANTS_PA { WVARIANT_PA(1, 4), WVARIANT_PA(2, 4), WVARIANT_PA(3, 4), WVARIANT_PA(4, 2), WVARIANT_PA(4, 4), WVARIANT_PA(5, 6), \
+                       WVARIANT_PA(6, 6), WVARIANT_PA(7, 6), WVARIANT_PA(8, 4), WVARIANT_PA(8, 6), WVARIANT_PA(8, 8) }
+#ifdef __HIP_DEVICE_COMPILE__
+namespace { [[maybe_unused]] const WVariant kWVariantsPA_instantiate[] = WVARIANTS_PA; }
+#else
+extern const WVariant kWVariantsPA[] = WVARIANTS_PA;
+extern const int kNumWVariantsPA = sizeof(kWVariantsPA) / sizeof(kWVariantsPA[0]);
+#endif
+#endif
 #if WREG_PART == 0
 
 // Plan with A as a dense image in LDS (no tables): for matrices whose Gram term list does not fit -- dense A's, e.g. the LPs
@@ -1859,7 +2066,7 @@ static int wreg_plan_create_dense(int m, int n, int nnz, const double* val, cons
                                   hipStream_t st, WregPlan** out) {
     int vi = -1;
     for (int i = 0; i < kNumWVariants; i++)
-        if (kWVariants[i].da && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
+        if (kWVariants[i].da && !kWVariants[i].pa && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
     if (vi < 0) return 1;
     const int MB = kWVariants[vi].mb, NQ = kWVariants[vi].nq, MP = 16 * MB;
     // identity tail?
@@ -1897,21 +2104,24 @@ static int wreg_plan_create_dense(int m, int n, int nnz, const double* val, cons
 }
 
 static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
-                                   hipStream_t st, WregPlan** out);
+                                   bool pa, hipStream_t st, WregPlan** out);
 
-int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds, int pa,
                      hipStream_t st, WregPlan** out) {
-    const int rc = wreg_plan_create_tables(m, n, nnz, val, ptr, col, max_lds, st, out);
+    if (pa) return wreg_plan_create_tables(m, n, nnz, val, ptr, col, max_lds, true, st, out);
+    const int rc = wreg_plan_create_tables(m, n, nnz, val, ptr, col, max_lds, false, st, out);
     if (rc != 1) return rc;
     return wreg_plan_create_dense(m, n, nnz, val, ptr, col, max_lds, st, out);
 }
 
+// pa: the structure-only tables of the per-problem-A variants (the values `val` only stand in where a table still wants
+// one; no kernel of those variants reads them)
 static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
-                                   hipStream_t st, WregPlan** out) {
+                                   bool pa, hipStream_t st, WregPlan** out) {
     int vi = -1;
     for (int i = 0; i < kNumWVariants; i++)
-        if (!kWVariants[i].da && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
-    if (vi < 0 || nnz >= 65536) return 1;
+        if (!kWVariants[i].da && kWVariants[i].pa == pa && m <= 16 * kWVariants[i].mb && n <= 64 * kWVariants[i].nq) { vi = i; break; }
+    if (vi < 0 || nnz >= 65535) return 1;
     const int MB = kWVariants[vi].mb, NQ = kWVariants[vi].nq;
     const int MP = 16 * MB, MPL = 64 * ((MP + 63) / 64), NP = 64 * NQ;
     WregPlan* P = new WregPlan();
@@ -1920,14 +2130,14 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
     T.m = m; T.n = n; T.nnz = nnz;
     // ---- column positions: the columns sorted by length (longest first) are dealt to positions 0, 1, ...; position p
     //      is element p % 64 of N-vector register p / 64, so every register holds 64 columns of similar length ----
-    std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<int> cptr(n + 1, 0), crow(nnz), csc_src(nnz);
     std::vector<double> csc_val(nnz);
     for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
     for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
     {
         std::vector<int> fill(cptr.begin(), cptr.end() - 1);
         for (int i = 0; i < m; i++)
-            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; csc_val[p] = val[e]; }
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; csc_val[p] = val[e]; csc_src[p] = e; }
     }
     std::vector<int> order(n), posof(n);
     for (int j = 0; j < n; j++) order[j] = j;
@@ -1954,18 +2164,20 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
     T.ctot = ctot;
     std::vector<double> ec_val((size_t)std::max(ctot, 1) * 64, 0.0);
     std::vector<unsigned short> ec_row((size_t)std::max(ctot, 1) * 64, 0);
+    std::vector<unsigned short> ec_src((size_t)std::max(ctot, 1) * 64, (unsigned short)nnz);      // padded slots: the zero entry
     for (int p = 0; p < n; p++) {
         const int j = order[p], q = p / 64, l = p % 64;
         for (int e = cptr[j], t = 0; e < cptr[j + 1]; e++, t++) {
             ec_val[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = csc_val[e];
             ec_row[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = (unsigned short)crow[e];
+            ec_src[(size_t)(T.meta[META_COFF + q] + t) * 64 + l] = (unsigned short)csc_src[e];
         }
     }
     // ---- Gram entries (strictly lower triangle of M): off-diagonal blocks grouped by staging chunk (HB blocks of the
     //      linear block order each); the entries inside the diagonal blocks go to their slots in the W area, as part of
     //      the last chunk's group when that chunk ends in front of the W area, else as a group of their own.  All
     //      destinations are offsets from the start of the stage. ----
-    struct Term { int group, dst, colj; double w; };
+    struct Term { int group, dst, colj; double w; int ia, ib; };
     std::vector<Term> terms;
     const int nblk = MB * (MB - 1) / 2, nchunk = (nblk + HB - 1) / HB;
     const bool merge_diag = nblk > 0 && (nblk - HB * (nchunk - 1)) * 256 <= stage_d(NQ);      // = WGeo<MB>::MERGE_DIAG(NQ)
@@ -1977,10 +2189,10 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
                 const int i = crow[a], k = crow[b2];   // rows ascend inside a column: i > k
                 const int K = k / 16, I = i / 16, il = i % 16, kl = k % 16;
                 if (I == K) {          // diagonal block K: element [il][kl] of the packed lower triangle in slot K
-                    terms.push_back({diag_group, stage_d(NQ) + K * WL + il * (il + 1) / 2 + kl, posof[j], csc_val[a] * csc_val[b2]});
+                    terms.push_back({diag_group, stage_d(NQ) + K * WL + il * (il + 1) / 2 + kl, posof[j], csc_val[a] * csc_val[b2], csc_src[a], csc_src[b2]});
                 } else {               // block (K, I) of U: element [kl][il] of block bix % HB of chunk bix / HB
                     const int bx = K * MB - K * (K + 1) / 2 + (I - K - 1);
-                    terms.push_back({bx / HB, (bx % HB) * 256 + kl * 16 + il, posof[j], csc_val[a] * csc_val[b2]});
+                    terms.push_back({bx / HB, (bx % HB) * 256 + kl * 16 + il, posof[j], csc_val[a] * csc_val[b2], csc_src[a], csc_src[b2]});
                 }
                 if (terms.size() > ((size_t)1 << 22)) { delete P; return 1; }
             }
@@ -1990,7 +2202,8 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
     std::stable_sort(terms.begin(), terms.end(), [](const Term& a, const Term& b) {
         return a.group != b.group ? a.group < b.group : a.dst < b.dst; });
     std::vector<double> t_w;
-    std::vector<unsigned> t_cd;
+    std::vector<unsigned> t_cd, t_ab;
+    const unsigned ab_zero = (unsigned)nnz | ((unsigned)nnz << 16);       // padded records: 0 x 0
     std::vector<int> lev(1, 0), gl(ngroup + 1, 0);
     {
         size_t t0 = 0;
@@ -2006,7 +2219,10 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
                 ent.push_back({t, u}); t = u;
             }
             if (!ent.empty()) {
-                for (auto& e : ent) { t_w.push_back(terms[e.first].w); t_cd.push_back((unsigned)terms[e.first].colj | ((unsigned)terms[e.first].dst << 16)); }
+                for (auto& e : ent) {
+                    t_w.push_back(terms[e.first].w); t_cd.push_back((unsigned)terms[e.first].colj | ((unsigned)terms[e.first].dst << 16));
+                    t_ab.push_back((unsigned)terms[e.first].ia | ((unsigned)terms[e.first].ib << 16));
+                }
                 lev.push_back((int)t_w.size());
                 for (size_t r = 0;; r++) {
                     bool any = false;
@@ -2018,6 +2234,7 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
                             const bool have = f + k < e.second;
                             t_w.push_back(have ? terms[f + k].w : 0.0);
                             t_cd.push_back((have ? (unsigned)terms[f + k].colj : 0u) | ((unsigned)terms[e.first].dst << 16));
+                            t_ab.push_back(have ? ((unsigned)terms[f + k].ia | ((unsigned)terms[f + k].ib << 16)) : ab_zero);
                         }
                     }
                     if (!any) break;
@@ -2030,30 +2247,43 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
     }
     for (int g = 0; g <= ngroup; g++) T.meta[META_SEG + g] = gl[g];
     T.n_lev = (int)lev.size() - 1; T.n_term = (int)t_w.size();
-    if (t_w.empty()) { t_w.push_back(0.0); t_cd.push_back(0); }
+    if (t_w.empty()) { t_w.push_back(0.0); t_cd.push_back(0); t_ab.push_back(ab_zero); }
     // ---- LDS plan ----
-    size_t off = 0;
-    auto take = [&](size_t bytes) { off = (off + 15) & ~(size_t)15; const size_t o_ = off; off += bytes; return (int)o_; };
-    T.o_csr_val = take(sizeof(double) * csr_val.size());
-    T.o_ec_val = take(sizeof(double) * ec_val.size());
-    T.o_t_w = take(sizeof(double) * t_w.size());
-    T.wave_doubles = stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL;
-    T.o_wave = take(sizeof(double) * 4 * (size_t)T.wave_doubles);
-    T.o_lev = take(sizeof(int) * lev.size());
-    T.o_t_cd = take(sizeof(unsigned) * t_cd.size());
-    T.o_colmap = take(sizeof(unsigned) * colmap.size());
-    T.o_meta = take(sizeof(int) * META_N);
-    T.o_csr_col = take(sizeof(unsigned short) * csr_col.size());
-    T.o_csr_ptr = take(sizeof(unsigned short) * csr_ptr.size());
-    T.o_csr_len = take(sizeof(unsigned short) * csr_len.size());
-    T.o_ec_row = take(sizeof(unsigned short) * ec_row.size());
-    T.lds_bytes = (int)((off + 15) & ~(size_t)15);
-    if (T.lds_bytes > max_lds) { delete P; return 1; }
+    // PA: no value tables; every wave carries nnzp doubles of its LP's values behind its area, and as many waves share a
+    // workgroup as the LDS takes (three at config 5's structure: 3 x 37.6 KB + 22 KB of structure tables)
+    T.pa = pa ? 1 : 0;
+    T.nnzp = pa ? ((nnz + 1 + 1) & ~1) : 0;
+    T.wave_doubles = stage_d(NQ) + 64 * NQ + 5 * MP + MB * WL + T.nnzp;
+    int wpb = 4;
+    for (;;) {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { off = (off + 15) & ~(size_t)15; const size_t o_ = off; off += bytes; return (int)o_; };
+        if (!pa) {
+            T.o_csr_val = take(sizeof(double) * csr_val.size());
+            T.o_ec_val = take(sizeof(double) * ec_val.size());
+            T.o_t_w = take(sizeof(double) * t_w.size());
+        }
+        T.o_wave = take(sizeof(double) * (size_t)wpb * (size_t)T.wave_doubles);
+        T.o_lev = take(sizeof(int) * lev.size());
+        T.o_t_cd = take(sizeof(unsigned) * t_cd.size());
+        if (pa) T.o_t_ab = take(sizeof(unsigned) * t_ab.size());
+        T.o_colmap = take(sizeof(unsigned) * colmap.size());
+        T.o_meta = take(sizeof(int) * META_N);
+        T.o_csr_col = take(sizeof(unsigned short) * csr_col.size());
+        T.o_csr_ptr = take(sizeof(unsigned short) * csr_ptr.size());
+        T.o_csr_len = take(sizeof(unsigned short) * csr_len.size());
+        T.o_ec_row = take(sizeof(unsigned short) * ec_row.size());
+        if (pa) T.o_ec_src = take(sizeof(unsigned short) * ec_src.size());
+        T.lds_bytes = (int)((off + 15) & ~(size_t)15);
+        if (T.lds_bytes <= max_lds) break;
+        if (!pa || wpb == 1) { delete P; return 1; }
+        wpb--;
+    }
     // ---- device copies ----
     std::vector<char> host;
     const size_t a1 = put(host, csr_val), a2 = put(host, ec_val), a3 = put(host, t_w), a4 = put(host, lev),
                  a5 = put(host, csr_col), a6 = put(host, csr_ptr), a7 = put(host, csr_len), a8 = put(host, ec_row),
-                 a9 = put(host, colmap), a11 = put(host, t_cd);
+                 a9 = put(host, colmap), a11 = put(host, t_cd), a12 = put(host, ec_src), a13 = put(host, t_ab);
     hipError_t e = hipMalloc(&P->dev_blob, host.size());
     if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -2065,7 +2295,8 @@ static int wreg_plan_create_tables(int m, int n, int nnz, const double* val, con
     T.csr_len = (const unsigned short*)(db + a7); T.ec_row = (const unsigned short*)(db + a8);
     T.colmap = (const unsigned*)(db + a9);
     T.t_cd = (const unsigned*)(db + a11);
-    P->mb = MB; P->nq = NQ; T.wpb = 4;
+    T.ec_src = (const unsigned short*)(db + a12); T.t_ab = (const unsigned*)(db + a13);
+    P->mb = MB; P->nq = NQ; P->pa = pa; T.wpb = wpb;
     *out = P;
     return 0;
 }
@@ -2082,31 +2313,31 @@ int wreg_variant(const WregPlan* p) { return p ? (p->da ? 2 : 1) : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)
-        if (kWVariants[i].mb == p->mb && kWVariants[i].nq == p->nq && kWVariants[i].da == p->da) return &kWVariants[i];
+        if (kWVariants[i].mb == p->mb && kWVariants[i].nq == p->nq && kWVariants[i].da == p->da && kWVariants[i].pa == p->pa) return &kWVariants[i];
     return nullptr;
 }
 
-hipError_t wreg_launch_solve(WregPlan* p, long B, const double* b, const double* c, double* x, double* y, double* z,
+hipError_t wreg_launch_solve(WregPlan* p, long B, const double* a_batch, const double* b, const double* c, double* x, double* y, double* z,
                              double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o,
                              int num_cu, hipStream_t st, int* grid_out) {
     const WVariant* v = find_variant(p);
-    if (!v) return hipErrorInvalidValue;
+    if (!v || (p->pa != (a_batch != nullptr))) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(defer, 0, sizeof(int), st);
     if (e != hipSuccess) return e;
     long cus = (long)num_cu - o.reserve_cus > 0 ? (long)num_cu - o.reserve_cus : 1;
     // the m <= 64 variants need fewer than half the registers (234 of 512 per lane): two workgroups per CU -- two waves per
     // SIMD -- where the LDS allows it
-    if (p->mb <= 4 && 2 * (long)p->tab.lds_bytes <= 160 * 1024) cus *= 2;
+    if (p->mb <= 4 && 2 * (long)p->tab.lds_bytes <= 160 * 1024 && p->tab.wpb == 4) cus *= 2;
     long grid = std::min(cus, (B + p->tab.wpb - 1) / p->tab.wpb);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
-    return ((o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve)(p->tab, B, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
+    return ((o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve)(p->tab, B, a_batch, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
 }
 
 hipError_t wreg_launch_newton(WregPlan* p, long B, const double* x, const double* z, const double* y, const double* b,
                               const double* c, double mu, double* dy, int* nref, DevOpts o, int num_cu, hipStream_t st) {
     const WVariant* v = find_variant(p);
-    if (!v) return hipErrorInvalidValue;
+    if (!v || !v->newton) return hipErrorInvalidValue;
     int* qhead = nullptr;
     hipError_t e = hipMallocAsync((void**)&qhead, sizeof(int), st);
     if (e != hipSuccess) return e;

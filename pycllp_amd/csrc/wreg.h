@@ -30,6 +30,13 @@ struct WregTab {
     int o_csr_val, o_ec_val, o_t_w, o_wave, o_lev, o_meta, o_csr_col, o_csr_ptr, o_csr_len, o_ec_row, o_colmap,
         o_t_cd;                                           // LDS byte offsets
     int wave_doubles, lds_bytes;
+    // per-problem values of A (PA variants; SparseMatrix.data[nproblems, nnz], pycllp/lp.py:16-54): the tables above hold
+    // the STRUCTURE only -- csr_val, ec_val and t_w are absent; every wavefront keeps the values of ITS LP (CSR order,
+    // nnzp = nnz + 1 rounded up to even doubles, entry [nnz] = 0 for the padded slots) behind its wave area, and finds an
+    // ELL slot's value through ec_src (CSR index of the slot) and a Gram term's weight as the product of the two entries
+    // t_ab names (CSR index of a_ij | CSR index of a_kj << 16)
+    int pa, nnzp, o_ec_src, o_t_ab;
+    const unsigned short* ec_src; const unsigned* t_ab;
     // dense variant (DA): no tables, A as a row-major image [img_rows][as] of its first nd columns (the remaining n - nd
     // columns are the identity, column nd + i = e_i, or there are none), as = nd rounded up to 8, + 1
     int nd, as, img_rows, o_img, wpb;
@@ -37,29 +44,34 @@ struct WregTab {
 };
 
 
-typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const double*, double*, double*, double*, double*,
-                                double*, int*, int*, int*, int*, DevOpts, int, hipStream_t);
+typedef hipError_t (*wsolve_fn)(const WregTab&, long, const double*, const double*, const double*, double*, double*, double*,
+                                double*, double*, int*, int*, int*, int*, DevOpts, int, hipStream_t);
 typedef hipError_t (*wnewton_fn)(const WregTab&, long, const double*, const double*, const double*, const double*,
                                  const double*, double, double*, int*, int*, DevOpts, int, hipStream_t);
 
-struct WVariant { int mb, nq; bool da; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
-// the dense-image variants live in the second translation unit (same source, -DWREG_PART=1), compiled in parallel
+struct WVariant { int mb, nq; bool da, pa; wsolve_fn solve, solve_hsd; wnewton_fn newton; };
+// the dense-image variants live in the second translation unit (same source, -DWREG_PART=1), the per-problem-A variants
+// in the third (-DWREG_PART=2), compiled in parallel
 extern const WVariant kWVariantsDA[];
 extern const int kNumWVariantsDA;
+extern const WVariant kWVariantsPA[];
+extern const int kNumWVariantsPA;
 
 struct WregPlan;   // host tables + device copies for one shared constraint matrix
 
 // Builds the plan from a host CSR copy of A (m rows, n columns, equality form).  Returns 0 and *out on success,
 // 1 when the register-resident kernel does not cover the problem (too many rows/columns, tables larger than LDS):
 // the caller then stays on ipm_block_kernel.  A positive hipError_t is returned as (1000 + error).
-int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds,
+// pa != 0: the plan of the per-problem-A variants (structure tables only; `val` is not read).
+int wreg_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds, int pa,
                      hipStream_t st, WregPlan** out);
 void wreg_plan_free(WregPlan* p);
 
 // Solve B LPs (same argument meaning as pycllp_hip_sparse_solve).  LPs whose factorisation would have needed the
 // Nocedal-Wright guard are NOT solved: their indices are appended to defer[1..] (defer[0] = count, zeroed here) and
 // their status is left at -1; the caller runs them through the guarded kernel afterwards.
-hipError_t wreg_launch_solve(WregPlan* p, long B, const double* b, const double* c, double* x, double* y, double* z,
+// a_batch: [B, nnz] values of every LP in the CSR order of the arrays the plan was built from (PA plans only, else null).
+hipError_t wreg_launch_solve(WregPlan* p, long B, const double* a_batch, const double* b, const double* c, double* x, double* y, double* z,
                              double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o,
                              int num_cu, hipStream_t st, int* grid_out);
 

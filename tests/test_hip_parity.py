@@ -1041,6 +1041,7 @@ def test_per_problem_values_of_A(name, hsd):
     lp.init(s)
     st = lp.solve(s)
     assert (st == 0).all()
+    assert s.launch_info()["kernel"] == "wave"       # round 3: per-problem values run on the wavefront-per-LP kernel too
     for k in range(B):
         r = port.dense_solve(lp.A.todense(k), lp.b[k:k + 1], lp.c[k:k + 1], flags=32 if hsd else 0)
         assert r["status"][0] == 0 and abs(int(s.iters[k]) - int(r["iters"][0])) <= 1
@@ -1048,6 +1049,34 @@ def test_per_problem_values_of_A(name, hsd):
         np.testing.assert_allclose(s.x[k], r["x"][0], rtol=1e-5, atol=1e-7)
     # the values matter: LP 0 solved with LP 1's matrix gives another optimum
     assert abs(s.primal_obj[0] - port.dense_solve(lp.A.todense(1), lp.b[:1], lp.c[:1])["pobj"][0]) > 1e-6
+
+
+@pytest.mark.parametrize("hsd", [False, True])
+def test_per_problem_values_of_A_against_the_reference_solver_and_the_block_kernel(hsd):
+    """tests/golden/config_perA_128x256.npz: the first 32 LPs of bench.py's `perA` workload (config 5's structure, every LP
+    its own values), each solved by the REFERENCE's hsd.c with its own matrix (tools/gen_golden.py per_problem_a_config) --
+    the reference pins this extension LP by LP although its LP classes refuse such a batch (lp.py:335-336).  Also: the
+    wave kernel's per-problem-A variant and the workgroup-per-LP kernel (PYCLLP_FLAG_BLOCK_KERNEL) agree, and a wave count
+    that does not divide the batch (three waves per workgroup at this structure) loses no LP."""
+    from pycllp_amd import _native
+    g = golden("config_perA_128x256.npz")
+    k, B = int(g["nobj"]), int(g["batch"])
+    A, b, c = problems.random_sparse_arrays(128, 256, B, density=0.025, seed=0)
+    nb = 1000 + 1                                                   # not a multiple of 3 or 4
+    rows, cols, data = problems.per_problem_values(A, nb, seed=7)
+    assert np.allclose(g["input_checksum"], [data[:k].sum(), b[:k].sum(), c[:k].sum()], rtol=1e-12)
+    lp = StandardLP(SparseMatrix(rows, cols, data), b[:nb], c[:nb], 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
+    lp.init(s)
+    st = lp.solve(s).copy()
+    info = s.launch_info()
+    assert info["kernel"] == "wave" and (st == 0).all()
+    assert rel_err(s.primal_obj[:k], g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj[:k], g["dobj"]).max() < OBJ_TOL
+    po, it = s.primal_obj.copy(), s.iters.copy()
+    blk = solver_registry["hip_sparse_primal_normal"](hsd=hsd, flags=_native.FLAG_BLOCK_KERNEL)
+    lp.init(blk)
+    assert (lp.solve(blk) == 0).all() and blk.launch_info()["kernel"] == "block"
+    assert rel_err(po, blk.primal_obj).max() < 1e-9 and np.abs(it.astype(int) - blk.iters).max() <= 1
 
 
 def test_general_lp_through_the_plugin():

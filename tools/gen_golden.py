@@ -152,13 +152,15 @@ def dense_image_config(m=100, n=80, nlp=64):
     print("dense config (%d,%d): %d LPs, status" % (m, n, nlp), np.bincount(g["status"]), "max internal gap", gap.max())
 
 
-def per_problem_a_config(m=128, n=256, density=0.025, nlp=32):
+def per_problem_a_config(m=128, n=256, density=0.025, nlp=32, batch=16384):
     """Per-problem values of A on config 5's structure.  The reference's LP classes refuse such a batch
     (lp.py:335-336) but its CPU solver takes ONE matrix per call: every LP is handed to hsd.c with ITS OWN matrix, which
-    pins the extension to the reference LP by LP.  Inputs come from problems.random_sparse_arrays / per_problem_values
-    (seed 0 / 7); a checksum pins them."""
+    pins the extension to the reference LP by LP.  The LPs are the FIRST `nlp` of bench.py's `perA` workload (`batch` LPs:
+    problems.random_sparse_arrays(seed 0) draws c after all of b, so the batch size is part of the recipe; values:
+    problems.per_problem_values, seed 7); a checksum pins them."""
     import scipy.sparse as sp
-    A, b, c = problems.random_sparse_arrays(m, n, nlp, density=density, seed=0)
+    A, b, c = problems.random_sparse_arrays(m, n, batch, density=density, seed=0)
+    b, c = b[:nlp], c[:nlp]
     rows, cols, data = problems.per_problem_values(A, nlp, seed=7)
     po, du, st = [], [], []
     for k in range(nlp):
@@ -167,7 +169,7 @@ def per_problem_a_config(m=128, n=256, density=0.025, nlp=32):
         po.append(g["pobj"][0]); du.append(g["dobj"][0]); st.append(g["status"][0])
     po, du = np.array(po), np.array(du)
     np.savez_compressed(os.path.join(OUT, "config_perA_%dx%d.npz" % (m, n)), m=m, n=n, density=density, seed=0, value_seed=7,
-                        nobj=nlp, input_checksum=np.array([data.sum(), b.sum(), c.sum()]),
+                        nobj=nlp, batch=batch, input_checksum=np.array([data.sum(), b.sum(), c.sum()]),
                         pobj=po, dobj=du, status=np.array(st, dtype=np.int8))
     print("per-problem-A config (%d,%d): %d LPs, status" % (m, n, nlp), np.bincount(st),
           "max gap", (np.abs(po - du) / np.maximum(1.0, np.abs(po))).max())
