@@ -1,0 +1,695 @@
+// ipm_big.hip -- LPs beyond the register-resident kernels: one LP per WORKGROUP (four wavefronts), 128 < m <= 256 rows
+// and/or 512 < n <= 1280 columns (equality form), the m x m normal-equations matrix and its LDL' factor as 16 x 16 blocks
+// in LDS when they fit (m <= ~144) and in an L2-resident workspace otherwise.
+//
+// Why: the reference's hosts take any (m, n) (pycllp/solvers/cl.py:28-83, 127-278; examples/random_problem.py:30-49 is run
+// with arbitrary sizes); the lane-group kernels stop at m = 32, the wavefront-per-LP kernel (ipm_wreg.hip) at m = 128 --
+// its factor fills the register file of a SIMD.  Beyond that one LP gets a whole compute unit:
+//   * M = A diag(x/z) A' and its factor are kept as the upper block triangle of U = L' in 16 x 16 blocks stored in the
+//     ACCUMULATOR layout of v_mfma_f64_16x16x4_f64 (element [4r + l/16][l%16] of a block = double r*64 + l): a block
+//     is loaded with four coalesced 512-byte reads straight into the registers an MFMA wants -- that layout is at once the
+//     B operand of the block and the A operand of its transpose (the algebra of ipm_wreg.hip, the blocks in memory instead
+//     of registers), so panel (Y_KI = L_KK^-1 M_KI) and trailing update (M_JI -= Y_KJ' D_K^-1 Y_KI) are MFMAs on loaded
+//     blocks with no layout conversion; the blocks of a stage are dealt round-robin to the four waves, three workgroup
+//     barriers per block column;
+//   * the diagonal block of a stage is factored by wave 0 in "lane = row" form with the fused 64-bit DPP FMA chain of the
+//     other kernels (chain_asm.inc), its inverse W_K goes to LDS for the panel and for the triangular solves;
+//   * the Gram matrix comes from a term list (sparse A: nnz-proportional, deterministic) or, for a dense A, from the
+//     matrix cores: the dense columns as a k-major image [k/4][row][4] in global memory (L2-resident, shared by all
+//     workgroups: every operand fetch of a wave is one contiguous 512-byte read), the identity columns of [A | I] as a
+//     diagonal update;
+//   * N-vectors in registers (thread = column, up to five per thread), m-vectors in LDS, mat-vecs on CSR / CSC copies of A
+//     read through L2, block substitution on wave 0.
+// Semantics = oracle/ipm_dense_ref.c (ipm_one_path / hsd_one_raw / newton_dy), like every other kernel of this library:
+// reference kernels replaced as in ipm_block.inc (pycllp/cl/primal_normal.cl:201-375, pycllp/cl/ldl.cl:314-712).
+// The Nocedal-Wright guard (ldl.cl:368) is recorded, not applied: an LP on which it would have bitten ends with
+// PYCLLP_STATUS_NUMERICAL (never observed on a positive semi-definite M; the smaller kernels defer such LPs to ipm_block_kernel).
+#include "big.h"
+
+namespace {
+
+constexpr int BT = 256;                  // threads per workgroup
+constexpr int BNC = BIG_MAX_N / BT;      // N-vector registers per thread
+
+struct BigTab {
+    int m, n, nnz, MB, dense, m_in_lds, lds_bytes;
+    int nd, ks, imgR, n_sl;              // dense mode: nd dense columns, ks = k-steps of 4 columns, image rows, identity columns behind them
+    const double* csr_val; const int* csr_ptr; const int* csr_col;   // A by rows
+    const double* csc_val; const int* csc_ptr; const int* csc_row;   // A by columns
+    const double* img;                   // [ks][imgR][4]
+    int n_ent;                           // term-list mode: entries (i, k), i >= k, of M with their terms a_ij a_kj, column j
+    const int* ent_dst; const int* ent_dst2; const int* ent_ptr; const double* term_w; const int* term_col;
+};
+
+__host__ __device__ inline int bidx(int K, int I) { return I * (I + 1) / 2 + K; }     // block (K, I), K <= I, of U = L'
+// offset of element [kl][il] inside a block
+__host__ __device__ inline int boff(int kl, int il) { return (kl >> 2) * 64 + (kl & 3) * 16 + il; }
+
+__device__ __forceinline__ double bsum(double v, double* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double bmax(double v, double* red, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// doubles of LDS the kernel carves (host and device agree through this one function)
+__host__ __device__ inline size_t big_lds_doubles(int MB, int n, bool m_in_lds) {
+    const size_t MP = 16 * (size_t)MB, NPv = ((size_t)n + 7) & ~(size_t)7;
+    return (m_in_lds ? (size_t)MB * (MB + 1) / 2 * 256 : 0) + (size_t)MB * 256 + 2 * NPv + 9 * MP + 272 + 256 + 32;
+}
+
+__global__ void __launch_bounds__(BT, 1)
+ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg, double* __restrict__ xg,
+               double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj, double* __restrict__ dobj,
+               int* __restrict__ status, int* __restrict__ iters, int* __restrict__ queue, double* ws, double nwt_mu,
+               double* __restrict__ nwt_dy, int* __restrict__ nwt_nref, DevOpts o) {
+    // nwt_dy != nullptr: stand-alone Newton step (solve_primal_normal, ldl.cl:602-653 / 656-712): x, z, y are INPUTS, mu is
+    // nwt_mu, one pass of the Newton machinery runs and dy (+ refinement passes used) is all that is stored
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, c16 = lane & 15;
+    const int m = T.m, n = T.n, MB = T.MB, MP = 16 * MB, nblk = MB * (MB + 1) / 2;
+    const int NPv = (n + 7) & ~7;
+    // ---- LDS carve-up (big_lds_doubles) ----
+    double* p_ = lds;
+    double* Mw = T.m_in_lds ? p_ : ws + (size_t)blockIdx.x * nblk * 256;      // the blocks (see header); generic pointer
+    if (T.m_in_lds) p_ += (size_t)nblk * 256;
+    double* wl = p_;  p_ += MB * 256;        // W_K = L_KK^-1, row-major 16 x 16
+    double* vx = p_;  p_ += NPv;             // staging of an N-vector for the CSR products
+    double* vd = p_;  p_ += NPv;             // d = x/z
+    double* ys = p_;  p_ += MP;              // y
+    double* bs = p_;  p_ += MP;              // b
+    double* um = p_;  p_ += MP;              // solve vector in/out
+    double* dyv = p_; p_ += MP;              // dy
+    double* rdv = p_; p_ += MP;              // 1/D
+    double* tdv = p_; p_ += MP;              // D^-1 t of the forward sweep
+    double* pv = p_;  p_ += MP;              // HSD: p
+    double* flr = p_; p_ += MP;              // HSD: per-column pivot floors
+    double* qv = p_;  p_ += MP;              // HSD: right-hand side of q
+    double* tile = p_; p_ += 272;            // diagonal block, stride 17
+    double* wsA = p_; p_ += 256;             // W_K in the A-operand layout (four doubles per lane of the panel's MFMAs)
+    double* red = p_;                        // [32] reduction scratch
+    const double* csr_val = T.csr_val; const int* csr_ptr = T.csr_ptr; const int* csr_col = T.csr_col;
+    const double* csc_val = T.csc_val; const int* csc_ptr = T.csc_ptr; const int* csc_row = T.csc_row;
+
+    const bool nwt = nwt_dy != nullptr;
+    const bool warm = nwt || (o.flags & PYCLLP_FLAG_WARM_START) != 0;
+    const bool autoscale = !nwt && (o.flags & PYCLLP_FLAG_AUTOSCALE) != 0;
+    const bool hsd = !nwt && (o.flags & PYCLLP_FLAG_HSD) != 0;
+    const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
+    const double nm = (double)(n + m);
+
+    // A'u for this thread's columns, u in LDS
+    auto At_cols = [&](const double* u, double (&out)[BNC]) {
+#pragma unroll
+        for (int k = 0; k < BNC; k++) {
+            const int j = tid + BT * k;
+            double acc = 0.0;
+            if (j < n) for (int p = csc_ptr[j]; p < csc_ptr[j + 1]; p++) acc = fma(csc_val[p], u[csc_row[p]], acc);
+            out[k] = acc;
+        }
+    };
+    // (A v)_i for row i = tid (< m), v in LDS
+    auto A_row = [&](const double* v) {
+        double acc = 0.0;
+        if (tid < m) for (int p = csr_ptr[tid]; p < csr_ptr[tid + 1]; p++) acc = fma(csr_val[p], v[csr_col[p]], acc);
+        return acc;
+    };
+
+    // ---- M = A diag(d) A' (d in vd) into the blocks ----
+    auto gram = [&]() {
+        if (T.dense) {
+            const size_t step = (size_t)T.imgR * 4;
+            for (int bi = wave; bi < nblk; bi += 4) {
+                int I = (int)((sqrtf(8.0f * (float)bi + 1.0f) - 1.0f) * 0.5f);
+                while ((I + 1) * (I + 2) / 2 <= bi) I++;
+                while (I * (I + 1) / 2 > bi) I--;
+                const int K = bi - I * (I + 1) / 2;
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                const double* pk = T.img + (size_t)(16 * K + c16) * 4 + q;
+                const double* pi = T.img + (size_t)(16 * I + c16) * 4 + q;
+#pragma unroll 4
+                for (int s = 0; s < T.ks; s++) {
+                    const double dk = vd[4 * s + q];
+                    const double ak = pk[(size_t)s * step], ai = pi[(size_t)s * step];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ak * dk, ai, acc, 0, 0, 0);
+                }
+                if (K == I) {      // identity columns of [A | I] and the padded rows (identity rows of M)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int gi = 16 * K + c16;
+                        if (4 * r + q == c16) {
+                            if (gi < m) { if (T.n_sl) acc[r] += vd[T.nd + gi]; }
+                            else acc[r] = 1.0;
+                        }
+                    }
+                }
+                double* blk = Mw + (size_t)bi * 256;
+#pragma unroll
+                for (int r = 0; r < 4; r++) blk[r * 64 + lane] = acc[r];
+            }
+            __syncthreads();
+            return;
+        }
+        for (int i = tid; i < nblk * 256; i += BT) Mw[i] = 0.0;
+        __syncthreads();
+        for (int e = tid; e < T.n_ent; e += BT) {
+            double acc = 0.0;
+            for (int t = T.ent_ptr[e]; t < T.ent_ptr[e + 1]; t++) acc = fma(T.term_w[t], vd[T.term_col[t]], acc);
+            Mw[T.ent_dst[e]] = acc;
+            const int d2 = T.ent_dst2[e];
+            if (d2 >= 0) Mw[d2] = acc;
+        }
+        for (int i = m + tid; i < MP; i += BT) Mw[(size_t)bidx(i >> 4, i >> 4) * 256 + boff(i & 15, i & 15)] = 1.0;
+        __syncthreads();
+    };
+
+    // ---- blocked LDL' of the blocks in place (see header).  RELF: the pivot floor of column j is flr[j].  Returns whether the
+    //      Nocedal-Wright guard would have bitten anywhere (workgroup-uniform). ----
+    auto factor = [&](double beta2, double floor_, bool relf) -> bool {
+        int viol = 0;
+        double ymax = 0.0;
+        for (int K = 0; K < MB; K++) {
+            if (wave == 0) {
+                const double* blk = Mw + (size_t)bidx(K, K) * 256;
+#pragma unroll
+                for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = blk[r * 64 + lane];
+                wave_lds_sync();
+                double Wd[16], Ld[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
+                const double myf = relf ? flr[16 * K + c16] : floor_;
+                double rdiag = 1.0, aD, rD;
+                {
+                    const double piv = bcast64<0>(Wd[0]);
+                    aD = fmax(fabs(piv), row_bcast<0>(myf));
+                    rD = fast_rcp(aD);
+                }
+                static_for<0, 16>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const double u = Wd[j];
+                    const bool below = c16 > j;
+                    viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
+                    const double nli = below ? -(u * rD) : 0.0;
+                    Ld[j] = nli;
+                    rdiag = (c16 == j) ? rD : rdiag;
+                    asm volatile("" : "+v"(rdiag), "+v"(viol));
+                    if constexpr (j < 15) {
+                        double aDn, rDn;
+                        chain_step_pipe_relf<j>(Wd, u, nli, 0.0, myf, aDn, rDn);
+                        aD = aDn; rD = rDn;
+                    }
+                });
+                if (q == 0) rdv[16 * K + c16] = rdiag;
+                // W = L_KK^-1: Ws[s] = W[row c16][column 4s + q] (the A-operand layout of the panel's MFMAs); Ld holds -L
+                double Ws[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
+                static_for<0, 15>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    winv_step<j>(Ws, Ld[j]);
+                });
+#pragma unroll
+                for (int s = 0; s < 4; s++) { wsA[s * 64 + lane] = Ws[s]; wl[K * 256 + c16 * 16 + 4 * s + q] = Ws[s]; }
+            }
+            __syncthreads();
+            // ---- panel: Y_KI = W_K M_KI = D_K L_IK' (blocks stay unscaled); guard test Y^2 > beta^2 D ----
+            double WsL[4], rDr[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) { WsL[s] = wsA[s * 64 + lane]; rDr[s] = rdv[16 * K + 4 * s + q]; }
+            for (int I = K + 1 + wave; I < MB; I += 4) {
+                double* blk = Mw + (size_t)bidx(K, I) * 256;
+                double mb[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) mb[s] = blk[s * 64 + lane];
+                double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(WsL[s], mb[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { ymax = fmax(ymax, acc[r] * acc[r] * rDr[r]); blk[r * 64 + lane] = acc[r]; }
+            }
+            __syncthreads();
+            // ---- trailing update: M_JI -= Y_KJ' D_K^-1 Y_KI, K < J <= I (the diagonal blocks included, in full) ----
+            int cnt = 0;
+            for (int J = K + 1; J < MB; J++) {
+                const double* yj = Mw + (size_t)bidx(K, J) * 256;
+                for (int I = J; I < MB; I++, cnt++) {
+                    if ((cnt & 3) != wave) continue;
+                    const double* yi = Mw + (size_t)bidx(K, I) * 256;
+                    double* mji = Mw + (size_t)bidx(J, I) * 256;
+                    double4_t acc;
+                    double yn[4], yb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { acc[r] = mji[r * 64 + lane]; yn[r] = -(yj[r * 64 + lane] * rDr[r]); yb[r] = yi[r * 64 + lane]; }
+#pragma unroll
+                    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yn[s], yb[s], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) mji[r * 64 + lane] = acc[r];
+                }
+            }
+            __syncthreads();
+        }
+        const double bad = bmax((viol != 0 || ymax > beta2) ? 1.0 : 0.0, red, tid);
+        return bad > 0.0;
+    };
+
+    // ---- um <- (L D L')^-1 um: block substitution on wave 0 (forms and reductions as in ipm_wreg.hip's solve()) ----
+    auto solve = [&]() {
+        __syncthreads();
+        if (wave == 0) {
+            for (int I = 0; I < MB; I++) {          // forward, row oriented: t_I = W_I (s_I - sum_{K<I} Y_KI' D_K^-1 t_K)
+                double p = 0.0;
+                for (int K = 0; K < I; K++) {
+                    const double* blk = Mw + (size_t)bidx(K, I) * 256;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p = fma(blk[r * 64 + lane], tdv[16 * K + 4 * r + q], p);
+                }
+                double rC = um[16 * I + c16];
+                if (I > 0) rC -= quad_sum(p);
+                double tR[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) tR[s] = row_sum(wl[I * 256 + (4 * s + q) * 16 + c16] * rC);
+                wave_lds_sync();
+                if (c16 == 0) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) { um[16 * I + 4 * s + q] = tR[s]; tdv[16 * I + 4 * s + q] = tR[s] * rdv[16 * I + 4 * s + q]; }
+                }
+                wave_lds_sync();
+            }
+            for (int K = MB - 1; K >= 0; K--) {     // backward: x_K = W_K' D_K^-1 (t_K - sum_{I>K} Y_KI x_I)
+                double pr[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int I = K + 1; I < MB; I++) {
+                    const double* blk = Mw + (size_t)bidx(K, I) * 256;
+                    const double xC = um[16 * I + c16];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) pr[r] = fma(blk[r * 64 + lane], xC, pr[r]);
+                }
+                double px = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    double v = um[16 * K + 4 * r + q];
+                    if (K < MB - 1) v -= row_sum(pr[r]);
+                    px = fma(wl[K * 256 + (4 * r + q) * 16 + c16], v * rdv[16 * K + 4 * r + q], px);
+                }
+                const double xk = quad_sum(px);
+                wave_lds_sync();
+                if (q == 0) um[16 * K + c16] = xk;
+                wave_lds_sync();
+            }
+        }
+        __syncthreads();
+    };
+
+    for (;;) {
+        // ---- next LP from the device-wide queue ----
+        __syncthreads();
+        if (tid == 0) ((int*)red)[60] = atomicAdd(queue, 1);
+        __syncthreads();
+        const long lp = ((int*)red)[60];
+        if (lp >= B) break;
+
+        double x[BNC], z[BNC], c[BNC];
+        bool ok[BNC];
+#pragma unroll
+        for (int k = 0; k < BNC; k++) {
+            const int j = tid + BT * k;
+            ok[k] = j < n;
+            c[k] = ok[k] ? cg[lp * n + j] : 0.0;
+            x[k] = (warm && ok[k]) ? xg[lp * n + j] : 1.0;
+            z[k] = (warm && ok[k]) ? zg[lp * n + j] : 1.0;
+        }
+        if (tid < MP) {
+            bs[tid] = (tid < m) ? bg[lp * m + tid] : 0.0;
+            ys[tid] = (tid < m) ? ((warm && yg) ? yg[lp * m + tid] : (hsd ? 0.0 : 1.0)) : 0.0;
+        }
+        __syncthreads();
+        double sb = 1.0, sc = 1.0;
+        if (autoscale) {   // solve with b/max|b| and c/max|c| (PYCLLP_FLAG_AUTOSCALE); undone when storing
+            double cm = 0.0;
+#pragma unroll
+            for (int k = 0; k < BNC; k++) cm = fmax(cm, fabs(c[k]));
+            sb = bmax((tid < m) ? fabs(bs[tid]) : 0.0, red, tid);
+            sc = bmax(cm, red, tid);
+            sb = (sb > 0.0) ? sb : 1.0; sc = (sc > 0.0) ? sc : 1.0;
+            if (tid < m) { bs[tid] = bs[tid] / sb; if (warm) ys[tid] = ys[tid] / sc; }
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                c[k] = c[k] / sc;
+                if (warm) { x[k] = x[k] / sb; z[k] = z[k] / sc; }
+            }
+            __syncthreads();
+        }
+        double c2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < BNC; k++) c2 = fma(c[k], c[k], c2);
+        const double nb2 = bsum((tid < m) ? bs[tid] * bs[tid] : 0.0, red, tid);
+        const double nc2 = bsum(c2, red, tid);
+        const double nbn = sqrt(nb2), ncn = sqrt(nc2);
+        const double tol_r = o.eps * (1.0 + nbn), tol_s = o.eps * (1.0 + ncn);
+        const double etol = o.refine_tol * (1.0 + nbn);
+        double tau = 1.0, kap = 1.0;
+        if (hsd && warm) {
+            double g0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < BNC; k++) g0 += ok[k] ? x[k] * z[k] : 0.0;
+            kap = bsum(g0, red, tid) / (double)n;
+        }
+        double normr0 = 1e300, norms0 = 1e300, po = 0.0, du = 0.0;
+        int stat = PYCLLP_STATUS_ITERATION_LIMIT, it = 0;
+
+        for (; it < o.max_iter; it++) {
+            // ---- residuals, gap, objectives (primal_normal.cl:30-48, 76-94, 245-248; tau-scaled on the embedding) ----
+            double v[BNC], sg[BNC];
+            At_cols(ys, v);
+            double s2 = 0.0, gam = 0.0, pp = 0.0;
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                const int j = tid + BT * k;
+                sg[k] = ok[k] ? c[k] * tau - v[k] + z[k] : 0.0;
+                s2 = fma(sg[k], sg[k], s2);
+                gam += ok[k] ? x[k] * z[k] : 0.0;
+                pp += ok[k] ? c[k] * x[k] : 0.0;
+                if (j < NPv) vx[j] = ok[k] ? x[k] : 0.0;
+            }
+            __syncthreads();
+            const double Ax = A_row(vx);
+            const double rho_i = (tid < m) ? bs[tid] * tau - Ax : 0.0;
+            const double dd = (tid < MP) ? bs[tid] * ys[tid] : 0.0;
+            const double norms = sqrt(bsum(s2, red, tid));
+            gam = bsum(gam, red, tid); po = bsum(pp, red, tid); du = bsum(dd, red, tid);
+            const double normr = sqrt(bsum(rho_i * rho_i, red, tid));
+            const double mu = nwt ? nwt_mu : (hsd ? o.delta * (gam + tau * kap) / (double)(n + 1) : o.delta * gam / nm);
+            const double phi = du - po + kap;
+            if (!nwt) {
+                if (hsd) {      // oracle hsd_one_raw: optimal, or a primal / dual ray
+                    const bool p_ray = po > 0.0 && fma(nbn, tau, normr) <= einf * po;
+                    const bool d_ray = du < 0.0 && fma(ncn, tau, norms) <= einf * -du;
+                    if (!(isfinite(normr) && isfinite(norms) && isfinite(gam) && isfinite(tau) && isfinite(kap))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+                    if (normr <= tol_r * tau && norms <= tol_s * tau && gam <= o.eps * tau * (tau + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; break; }
+                    if (p_ray || d_ray) {
+                        stat = (p_ray && d_ray) ? ((-du > po) ? PYCLLP_STATUS_PRIMAL_INFEASIBLE : PYCLLP_STATUS_DUAL_INFEASIBLE)
+                                                : (p_ray ? PYCLLP_STATUS_DUAL_INFEASIBLE : PYCLLP_STATUS_PRIMAL_INFEASIBLE);
+                        break;
+                    }
+                } else {        // primal_normal.cl:256-269; oracle ipm_one_path
+                    if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+                    if (normr <= tol_r && norms <= tol_s && gam <= o.eps * (1.0 + fabs(po))) { stat = PYCLLP_STATUS_OPTIMAL; break; }
+                    if (normr > 10.0 * normr0 && normr > PYCLLP_GROWTH_FLOOR * tol_r) { stat = PYCLLP_STATUS_PRIMAL_INFEASIBLE; break; }
+                    if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; break; }
+                }
+            }
+            // ---- d = x/z, t (plain path: c - A'y + mu/x; embedding: r1 = mu/x - z + eta sigma) ----
+            double d[BNC], t[BNC];
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                d[k] = ok[k] ? x[k] / z[k] : 0.0;
+                t[k] = ok[k] ? (hsd ? fma(eta, sg[k], mu / x[k] - z[k]) : c[k] - v[k] + mu / x[k]) : 0.0;
+            }
+            __syncthreads();      // every A_row read of vx is done
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                const int j = tid + BT * k;
+                if (j < NPv) { vx[j] = d[k] * t[k]; vd[j] = d[k]; }
+            }
+            __syncthreads();
+            // ---- right-hand side A(d t) - rho (embedding: A(d r1) - eta rho) and diag(M) from one pass over the row ----
+            double adt = 0.0, mdg = 0.0;
+            if (tid < m)
+                for (int p = csr_ptr[tid]; p < csr_ptr[tid + 1]; p++) {
+                    const double a = csr_val[p]; const int j = csr_col[p];
+                    adt = fma(a, vx[j], adt); mdg = fma(a * a, vd[j], mdg);
+                }
+            const double beta2 = bmax((tid < m) ? fabs(mdg) : 0.0, red, tid);     // ldl.cl:280-294
+            if (hsd) {
+                // M p = A(d c) - b first; q's right-hand side waits in qv
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < BNC; k++) { const int j = tid + BT * k; if (j < NPv) vx[j] = d[k] * c[k]; }
+                __syncthreads();
+                const double adc = A_row(vx);
+                if (tid < MP) {
+                    um[tid] = (tid < m) ? adc - bs[tid] : 0.0;
+                    qv[tid] = (tid < m) ? fma(-eta, rho_i, adt) : 0.0;
+                    flr[tid] = o.pivot_floor * o.pivot_floor * fabs(mdg);
+                }
+            } else if (tid < MP) um[tid] = (tid < m) ? adt - rho_i : 0.0;
+            __syncthreads();
+            gram();
+            const bool viol = factor(beta2, hsd ? 0.0 : o.pivot_floor, hsd);
+            if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+
+            double dx[BNC], w2[BNC];
+            double dtau = 0.0, etol_it = etol, rhot_i = rho_i;
+            int nref = 0;
+            if (hsd) {
+                // p, then q; dy = p dtau + q, dx = u dtau + v with u = d (c - A'p), v = d (r1 - A'q)
+                solve();
+                if (tid < MP) { pv[tid] = um[tid]; um[tid] = qv[tid]; }
+                double uu[BNC];
+                At_cols(pv, w2);
+#pragma unroll
+                for (int k = 0; k < BNC; k++) uu[k] = ok[k] ? c[k] - w2[k] : 0.0;
+                solve();
+                At_cols(um, w2);
+                double dsum = 0.0, nsum = 0.0;
+#pragma unroll
+                for (int k = 0; k < BNC; k++) {
+                    dx[k] = d[k] * (t[k] - w2[k]);
+                    dsum = fma(d[k] * uu[k], uu[k], dsum);
+                    nsum = fma(c[k], dx[k], nsum);
+                }
+                const double bq = bsum((tid < MP) ? bs[tid] * um[tid] : 0.0, red, tid);
+                const double den = bsum(dsum, red, tid) + kap / tau;
+                const double num = fma(eta, phi, mu / tau - kap) + bq - bsum(nsum, red, tid);
+                dtau = num / den;
+                if (tid < MP) dyv[tid] = fma(pv[tid], dtau, um[tid]);
+                rhot_i = (tid < m) ? fma(bs[tid], dtau, eta * rho_i) : 0.0;       // A dx - b dtau = eta rho
+#pragma unroll
+                for (int k = 0; k < BNC; k++) dx[k] = fma(d[k] * uu[k], dtau, dx[k]);
+                etol_it = o.refine_tol * (1.0 + nbn) * fmax(tau, kap);
+            } else {
+                solve();
+                if (tid < MP) dyv[tid] = um[tid];
+                At_cols(um, w2);
+#pragma unroll
+                for (int k = 0; k < BNC; k++) dx[k] = (t[k] - w2[k]) * d[k];
+            }
+            // ---- x-space refinement (oracle newton_dy): e = rho - A dx; M eta = e; dx += d A'eta; dy -= eta ----
+            for (;;) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < BNC; k++) { const int j = tid + BT * k; if (j < NPv) vx[j] = ok[k] ? dx[k] : 0.0; }
+                __syncthreads();
+                const double e_i = (tid < m) ? rhot_i - A_row(vx) : 0.0;
+                const double maxe = bmax(fabs(e_i), red, tid);
+                if (!(maxe > etol_it) || nref >= o.max_refine) break;
+                if (tid < MP) um[tid] = e_i;
+                solve();
+                if (tid < MP) dyv[tid] -= um[tid];
+                At_cols(um, w2);
+#pragma unroll
+                for (int k = 0; k < BNC; k++) dx[k] = fma(d[k], w2[k], dx[k]);
+                nref++;
+            }
+            const double bad = bmax((tid < MP && !isfinite(dyv[tid])) ? 1.0 : 0.0, red, tid);
+            if (nwt) {
+                if (tid < m) nwt_dy[lp * m + tid] = dyv[tid];
+                if (nwt_nref && tid == 0) nwt_nref[lp] = nref;
+                break;
+            }
+            if (bad > 0.0 || !isfinite(dtau)) { stat = PYCLLP_STATUS_NUMERICAL; break; }
+            // ---- step (primal_normal.cl:122-156; embedding: ratio test over x, z, tau, kappa) ----
+            const double dkap = hsd ? mu / tau - kap - kap / tau * dtau : 0.0;
+            double dz[BNC], th = hsd ? fmax(fmax(-dtau / tau, -dkap / kap), 0.0) : 0.0;
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                dz[k] = ok[k] ? (mu - z[k] * dx[k]) / x[k] - z[k] : 0.0;
+                if (ok[k]) th = fmax(th, fmax(-dz[k] / z[k], -dx[k] / x[k]));
+            }
+            th = bmax(th, red, tid);
+            const double theta = fmin(o.r / th, 1.0);
+            if (tid < MP) ys[tid] = fma(theta, dyv[tid], ys[tid]);
+#pragma unroll
+            for (int k = 0; k < BNC; k++) { x[k] = fma(theta, dx[k], x[k]); z[k] = fma(theta, dz[k], z[k]); }
+            if (hsd) { tau = fma(theta, dtau, tau); kap = fma(theta, dkap, kap); }
+            normr0 = normr; norms0 = norms;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (nwt) continue;
+        // HSD: optimal (and iteration-limit) points leave the homogeneous scaling (hsd.c:266-273); certificates stay
+        const double rt = (hsd && (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT)) ? 1.0 / tau : 1.0;
+#pragma unroll
+        for (int k = 0; k < BNC; k++) {
+            const int j = tid + BT * k;
+            if (ok[k]) { xg[lp * n + j] = x[k] * rt * sb; if (zg) zg[lp * n + j] = z[k] * rt * sc; }
+        }
+        if (yg && tid < m) yg[lp * m + tid] = ys[tid] * rt * sc;
+        if (tid == 0) {
+            if (pobj) pobj[lp] = po * rt * (sb * sc);
+            if (dobj) dobj[lp] = du * rt * (sb * sc);
+            status[lp] = stat;
+            if (iters) iters[lp] = it;
+        }
+    }
+}
+
+template <typename T>
+size_t put(std::vector<char>& host, const std::vector<T>& v) {
+    size_t off = (host.size() + 15) & ~(size_t)15;
+    host.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+}  // namespace
+
+struct BigPlan {
+    BigTab tab;
+    void* dev_blob = nullptr;
+    size_t ws_doubles_per_block = 0;
+};
+
+int big_plan_create(int m, int n, int nnz, const double* val, const int* ptr, const int* col, int max_lds, hipStream_t st,
+                    BigPlan** out) {
+    if (m > BIG_MAX_M || n > BIG_MAX_N || m < 1 || n < 1) return 1;
+    const int MB = (m + 15) / 16, MP = 16 * MB;
+    BigPlan* P = new BigPlan();
+    BigTab& T = P->tab;
+    memset(&T, 0, sizeof(T));
+    T.m = m; T.n = n; T.nnz = nnz; T.MB = MB;
+    // ---- CSC by counting sort (rows ascending inside a column) ----
+    std::vector<int> cptr(n + 1, 0), crow(nnz);
+    std::vector<double> cval(nnz);
+    for (int e = 0; e < nnz; e++) cptr[col[e] + 1]++;
+    for (int j = 0; j < n; j++) cptr[j + 1] += cptr[j];
+    {
+        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int i = 0; i < m; i++)
+            for (int e = ptr[i]; e < ptr[i + 1]; e++) { const int p = fill[col[e]]++; crow[p] = i; cval[p] = val[e]; }
+    }
+    // ---- identity tail (equality form of a StandardLP)? ----
+    bool sl = n > m;
+    {
+        std::vector<int> tail_cnt(sl ? m : 0, 0);
+        for (int i = 0; i < m && sl; i++)
+            for (int e = ptr[i]; e < ptr[i + 1]; e++)
+                if (col[e] >= n - m) { if (col[e] != n - m + i || val[e] != 1.0) sl = false; else tail_cnt[i]++; }
+        for (int i = 0; i < m && sl; i++) if (tail_cnt[i] != 1) sl = false;
+    }
+    const int nd = sl ? n - m : n;
+    // ---- Gram by term list or on the matrix cores?  terms = sum over columns of len (len + 1) / 2 products per Newton step,
+    //      against MP^2 / 2 * nd for the dense product at the 8x higher rate of the matrix pipe over a gather-bound loop ----
+    double n_terms = 0.0;
+    for (int j = 0; j < n; j++) { const double l = cptr[j + 1] - cptr[j]; n_terms += l * (l + 1) / 2; }
+    T.dense = n_terms > 0.125 * (double)MP * MP * nd ? 1 : 0;
+    std::vector<double> img;
+    std::vector<int> ent_dst, ent_dst2, ent_ptr, term_col;
+    std::vector<double> term_w;
+    if (T.dense) {
+        T.nd = nd; T.n_sl = n - nd; T.ks = (nd + 3) / 4; T.imgR = MP;
+        img.assign((size_t)T.ks * MP * 4, 0.0);
+        for (int i = 0; i < m; i++)
+            for (int e = ptr[i]; e < ptr[i + 1]; e++)
+                if (col[e] < nd) img[((size_t)(col[e] >> 2) * MP + i) * 4 + (col[e] & 3)] = val[e];
+    } else {
+        struct Term { int key, colj; double w; };
+        std::vector<Term> terms;
+        for (int j = 0; j < n; j++)
+            for (int a = cptr[j]; a < cptr[j + 1]; a++)
+                for (int b2 = cptr[j]; b2 <= a; b2++) {
+                    const int i = crow[a], k = crow[b2];     // rows ascend inside a column: i >= k
+                    terms.push_back({i * m + k, j, cval[a] * cval[b2]});
+                    if (terms.size() > ((size_t)1 << 24)) { delete P; return 1; }
+                }
+        std::stable_sort(terms.begin(), terms.end(), [](const Term& x, const Term& y) { return x.key < y.key; });
+        term_col.resize(terms.size()); term_w.resize(terms.size());
+        for (size_t t = 0; t < terms.size(); t++) {
+            if (t == 0 || terms[t].key != terms[t - 1].key) {
+                const int i = terms[t].key / m, k = terms[t].key % m;
+                const int K = k >> 4, I = i >> 4, kl = k & 15, il = i & 15;
+                ent_dst.push_back(bidx(K, I) * 256 + boff(kl, il));
+                ent_dst2.push_back((K == I && kl != il) ? bidx(K, K) * 256 + boff(il, kl) : -1);
+                ent_ptr.push_back((int)t);
+            }
+            term_col[t] = terms[t].colj; term_w[t] = terms[t].w;
+        }
+        ent_ptr.push_back((int)terms.size());
+        T.n_ent = (int)ent_dst.size();
+    }
+    // ---- LDS plan: the blocks in LDS when they fit ----
+    T.m_in_lds = big_lds_doubles(MB, n, true) * sizeof(double) <= (size_t)max_lds ? 1 : 0;
+    const size_t lds = big_lds_doubles(MB, n, T.m_in_lds != 0) * sizeof(double);
+    if (lds > (size_t)max_lds) { delete P; return 1; }
+    T.lds_bytes = (int)lds;
+    P->ws_doubles_per_block = T.m_in_lds ? 0 : (size_t)MB * (MB + 1) / 2 * 256;
+    // ---- device copies ----
+    std::vector<char> host;
+    std::vector<double> csr_val(val, val + nnz);
+    std::vector<int> csr_ptr(ptr, ptr + m + 1), csr_col(col, col + nnz);
+    const size_t a1 = put(host, csr_val), a2 = put(host, csr_ptr), a3 = put(host, csr_col), a4 = put(host, cval),
+                 a5 = put(host, cptr), a6 = put(host, crow), a7 = put(host, img), a8 = put(host, ent_dst),
+                 a9 = put(host, ent_dst2), a10 = put(host, ent_ptr), a11 = put(host, term_w), a12 = put(host, term_col);
+    hipError_t e = hipMalloc(&P->dev_blob, host.size());
+    if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { if (P->dev_blob) (void)hipFree(P->dev_blob); delete P; return 1000 + (int)e; }
+    char* db = (char*)P->dev_blob;
+    T.csr_val = (const double*)(db + a1); T.csr_ptr = (const int*)(db + a2); T.csr_col = (const int*)(db + a3);
+    T.csc_val = (const double*)(db + a4); T.csc_ptr = (const int*)(db + a5); T.csc_row = (const int*)(db + a6);
+    T.img = (const double*)(db + a7);
+    T.ent_dst = (const int*)(db + a8); T.ent_dst2 = (const int*)(db + a9); T.ent_ptr = (const int*)(db + a10);
+    T.term_w = (const double*)(db + a11); T.term_col = (const int*)(db + a12);
+    *out = P;
+    return 0;
+}
+
+void big_plan_free(BigPlan* p) {
+    if (!p) return;
+    if (p->dev_blob) (void)hipFree(p->dev_blob);
+    delete p;
+}
+
+int big_lds_bytes(const BigPlan* p) { return p ? p->tab.lds_bytes : 0; }
+int big_dense_mode(const BigPlan* p) { return p ? p->tab.dense : 0; }
+
+static hipError_t big_launch(BigPlan* p, long B, const double* b, const double* c, double* x, double* y, double* z, double* pobj,
+                             double* dobj, int* status, int* iters, int* qhead, double mu, double* nwt_dy, int* nwt_nref,
+                             DevOpts o, int num_cu, hipStream_t st, int* grid_out) {
+    long cus = (long)num_cu - o.reserve_cus > 0 ? (long)num_cu - o.reserve_cus : 1;
+    long grid = std::min(cus, B);
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = (int)grid;
+    hipError_t e = set_dyn_lds((const void*)ipm_big_kernel, p->tab.lds_bytes);
+    if (e != hipSuccess) return e;
+    double* ws = nullptr;
+    if (p->ws_doubles_per_block) {
+        e = hipMallocAsync((void**)&ws, sizeof(double) * p->ws_doubles_per_block * (size_t)grid, st);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(ipm_big_kernel, dim3((unsigned)grid), dim3(BT), p->tab.lds_bytes, st, p->tab, B, b, c, x, y, z, pobj, dobj,
+                       status, iters, qhead, ws, mu, nwt_dy, nwt_nref, o);
+    e = hipGetLastError();
+    if (ws) { hipError_t e2 = hipFreeAsync(ws, st); if (e == hipSuccess) e = e2; }
+    return e;
+}
+
+hipError_t big_launch_solve(BigPlan* p, long B, const double* b, const double* c, double* x, double* y, double* z,
+                            double* pobj, double* dobj, int* status, int* iters, int* qhead, DevOpts o, int num_cu,
+                            hipStream_t st, int* grid_out) {
+    return big_launch(p, B, b, c, x, y, z, pobj, dobj, status, iters, qhead, 0.0, nullptr, nullptr, o, num_cu, st, grid_out);
+}
+
+hipError_t big_launch_newton(BigPlan* p, long B, const double* x, const double* z, const double* y, const double* b,
+                             const double* c, double mu, double* dy, int* nref, int* qhead, DevOpts o, int num_cu,
+                             hipStream_t st) {
+    return big_launch(p, B, b, c, (double*)x, (double*)y, (double*)z, nullptr, nullptr, nullptr, nullptr, qhead, mu, dy, nref, o,
+                      num_cu, st, nullptr);
+}

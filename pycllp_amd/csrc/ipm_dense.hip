@@ -24,6 +24,7 @@
 // reference algorithm with the SURVEY section 8(a) picks: relative stopping tolerance, DELTA/R of the
 // OpenCL kernel, Nocedal-Wright diagonal guard, |r|-driven iterative refinement, NaN guard.
 #include "wreg.h"
+#include "big.h"
 #include <mutex>
 
 // ------------------------------------------------------------------------------------------------
@@ -767,6 +768,7 @@ struct pycllp_hip_sparse {
     int lds_with_a = 0;     // LDS bytes with A's arrays in LDS (what per-problem values need), 0 when that does not fit
     int last_wreg = 0;      // 1 when the last solve ran on the wave kernel
     WregPlan* wreg = nullptr;     // tables of the register-resident wave kernel (ipm_wreg.hip), or nullptr when it does not cover A
+    BigPlan* big = nullptr;       // LPs beyond m = 128 / n = 512: the workgroup-per-LP kernel of ipm_big.hip serves the handle alone
     WregPlan* wreg_pa = nullptr;  // its per-problem-A plan (structure tables only), built by the first pycllp_hip_sparse_solve_batch
     WregPlan* last_plan = nullptr;
     bool wreg_pa_tried = false;
@@ -802,8 +804,8 @@ void pycllp_hip_default_opts(pycllp_hip_opts* o) {
     o->reserve_cus = 0;
 }
 
-int pycllp_hip_dense_max_rows(void) { return BLK_MAX_M; }   // m <= 32, n <= 128: lane-group kernels; beyond: the sparse path's kernels
-int pycllp_hip_dense_max_cols(void) { return BLK_MAX_N; }
+int pycllp_hip_dense_max_rows(void) { return BIG_MAX_M; }   // m <= 32, n <= 128: lane-group kernels; beyond: the sparse path's kernels
+int pycllp_hip_dense_max_cols(void) { return BIG_MAX_N; }
 
 int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycllp_hip_dense** handle) {
     if (!A_dev || !handle || m <= 0 || n <= 0) return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_init: bad argument");
@@ -812,11 +814,12 @@ int pycllp_hip_dense_init(int m, int n, const double* A_dev, void* stream, pycll
         if (m <= kVariants[i].mp && n <= kVariants[i].np) { vi = i; break; }
     if (vi < 0) {
         // Beyond the lane-group kernels (m <= 32, n <= 128).  The reference's dense host has no size limit
-        // (pycllp/solvers/cl.py:28-83; its own kernel test runs m = 100, N = 180): up to m = 128, n = 512 the LP is handed
-        // to the kernels of the sparse path -- the structural non-zeros of the dense A become its CSR arrays.
-        if (m > BLK_MAX_M || n > BLK_MAX_N) {
+        // (pycllp/solvers/cl.py:28-83; its own kernel test runs m = 100, N = 180): up to m = 256, n = 1280 the LP is handed
+        // to the kernels of the sparse path -- the structural non-zeros of the dense A become its CSR arrays (m <= 128,
+        // n <= 512: the wavefront-per-LP kernel on a dense image; beyond: the workgroup-per-LP kernel of ipm_big.hip).
+        if (m > BIG_MAX_M || n > BIG_MAX_N) {
             snprintf(g_err, sizeof(g_err), "pycllp_hip_dense_init: (m=%d, n=%d) exceeds the compiled kernels (m<=%d, n<=%d)", m, n,
-                     BLK_MAX_M, BLK_MAX_N);
+                     BIG_MAX_M, BIG_MAX_N);
             return PYCLLP_E_UNSUPPORTED;
         }
         hipStream_t st = (hipStream_t)stream;
@@ -997,9 +1000,9 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
                            const int* Aindices_dev, void* stream, pycllp_hip_sparse** handle) {
     if (!handle || !Adata_dev || !Aindptr_dev || !Aindices_dev || m <= 0 || n <= 0 || nnz <= 0)
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: bad argument");
-    if (m > BLK_MAX_M || n > BLK_MAX_N) {
-        snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_init: (m=%d, n=%d) exceeds the compiled kernel (m<=%d, n<=%d)", m, n,
-                 BLK_MAX_M, BLK_MAX_N);
+    if (m > BIG_MAX_M || n > BIG_MAX_N) {
+        snprintf(g_err, sizeof(g_err), "pycllp_hip_sparse_init: (m=%d, n=%d) exceeds the compiled kernels (m<=%d, n<=%d)", m, n,
+                 BIG_MAX_M, BIG_MAX_N);
         return PYCLLP_E_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1012,6 +1015,32 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     if (ptr[0] != 0 || ptr[m] != nnz) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: malformed CSR row pointer");
     for (int i = 0; i < m; i++) if (ptr[i + 1] < ptr[i]) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: malformed CSR row pointer");
     for (int e = 0; e < nnz; e++) if (col[e] < 0 || col[e] >= n) return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_init: column index out of range");
+    if (m > BLK_MAX_M || n > BLK_MAX_N) {
+        // beyond the wavefront-per-LP and block kernels: the workgroup-per-LP kernel of ipm_big.hip (blocks of the factor in
+        // LDS or an L2-resident workspace)
+        pycllp_hip_sparse* hb = new (std::nothrow) pycllp_hip_sparse();
+        if (!hb) return set_err(PYCLLP_E_NOMEM, "pycllp_hip_sparse_init: out of host memory");
+        int devb = 0;
+        hipDeviceProp_t propb;
+        hipError_t eb = hipGetDevice(&devb);
+        if (eb == hipSuccess) eb = hipGetDeviceProperties(&propb, devb);
+        if (eb == hipSuccess) eb = hb->ring.create();
+        if (eb != hipSuccess) { hb->ring.destroy(); delete hb; return set_err((int)eb, "pycllp_hip_sparse_init (large LP)"); }
+        hb->num_cu = propb.multiProcessorCount;
+        int max_lds_b = (int)propb.maxSharedMemoryPerMultiProcessor;
+        if (max_lds_b > 160 * 1024 || max_lds_b <= 0) max_lds_b = 160 * 1024;
+        hb->max_lds = max_lds_b;
+        hb->desc.m = m; hb->desc.n = n; hb->desc.nnz = nnz;
+        const int rc = big_plan_create(m, n, nnz, val.data(), ptr.data(), col.data(), max_lds_b, st, &hb->big);
+        if (rc != 0) {
+            hb->ring.destroy(); delete hb;
+            if (rc >= 1000) return set_err(rc - 1000, "big_plan_create");
+            return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_init: the LP does not fit the large-LP kernel");
+        }
+        hb->lds = big_lds_bytes(hb->big);
+        *handle = hb;
+        return 0;
+    }
     // CSC by counting sort (rows ascending inside a column)
     std::vector<int> cptr(n + 1, 0), crow(nnz), csrc(nnz);
     std::vector<double> cval(nnz);
@@ -1118,6 +1147,20 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
     hipStream_t st = (hipStream_t)stream;
+    if (h->big) {
+        if (a_batch) return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values of A stop at m = 128, n = 512");
+        int* qb = nullptr; unsigned sb_ = 0; int grid_b = 0;
+        hipError_t eb = h->ring.acquire(st, &qb, &sb_);
+        if (eb == hipSuccess) {
+            eb = big_launch_solve(h->big, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qb, o,
+                                  h->num_cu, st, &grid_b);
+            hipError_t er = h->ring.release(sb_, st);
+            if (eb == hipSuccess) eb = er;
+        }
+        { std::lock_guard<std::mutex> g(h->info_mu); h->last_wreg = 0; h->last_plan = nullptr; h->grid = grid_b; }
+        if (eb != hipSuccess) return set_err((int)eb, "ipm_big_kernel launch");
+        return 0;
+    }
     int* worklist = nullptr;
     int grid_w = 0;
     if (a_batch && !h->lds_with_a)
@@ -1199,6 +1242,17 @@ int pycllp_hip_sparse_newton(pycllp_hip_sparse* h, long B, const double* x_dev, 
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_newton: bad argument");
     DevOpts o = to_dev(opts);
     hipStream_t st = (hipStream_t)stream;
+    if (h->big) {
+        int* qb = nullptr; unsigned sb_ = 0;
+        hipError_t eb = h->ring.acquire(st, &qb, &sb_);
+        if (eb == hipSuccess) {
+            eb = big_launch_newton(h->big, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, qb, o, h->num_cu, st);
+            hipError_t er = h->ring.release(sb_, st);
+            if (eb == hipSuccess) eb = er;
+        }
+        if (eb != hipSuccess) return set_err((int)eb, "ipm_big_kernel (Newton mode) launch");
+        return 0;
+    }
     if (h->wreg && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL)) {
         hipError_t e = wreg_launch_newton(h->wreg, B, x_dev, z_dev, y_dev, b_dev, c_dev, mu, dy_dev, nrefine_dev, o, h->num_cu, st);
         if (e != hipSuccess) return set_err((int)e, "newton_wreg_kernel launch");
@@ -1229,7 +1283,7 @@ int pycllp_hip_sparse_launch_info(const pycllp_hip_sparse* h, int* grid, int* bl
     if (grid) *grid = h->grid;
     if (block) *block = h->last_wreg ? wreg_block_threads(h->last_plan) : BLK_T;
     if (lds_bytes) *lds_bytes = h->last_wreg ? wreg_lds_bytes(h->last_plan) : h->lds;
-    if (kernel) *kernel = h->last_wreg ? wreg_variant(h->last_plan) : 0;
+    if (kernel) *kernel = h->big ? (big_dense_mode(h->big) ? 4 : 3) : (h->last_wreg ? wreg_variant(h->last_plan) : 0);
     return 0;
 }
 
@@ -1288,11 +1342,12 @@ void pycllp_hip_sparse_free(pycllp_hip_sparse* h) {
     h->ring.destroy();
     wreg_plan_free(h->wreg);
     wreg_plan_free(h->wreg_pa);
+    big_plan_free(h->big);
     delete h;
 }
 
-int pycllp_hip_sparse_max_rows(void) { return BLK_MAX_M; }
-int pycllp_hip_sparse_max_cols(void) { return BLK_MAX_N; }
+int pycllp_hip_sparse_max_rows(void) { return BIG_MAX_M; }
+int pycllp_hip_sparse_max_cols(void) { return BIG_MAX_N; }
 
 void pycllp_hip_dense_free(pycllp_hip_dense* h) {
     if (!h) return;

@@ -314,6 +314,61 @@ __device__ __forceinline__ double dot16_bcast(double src, const double* l) {
     return a;
 }
 
+// ---- cross-lane helpers ----------------------------------------------------------------------------------------
+// v[l] + v[l ^ 16], then + the other 32 lanes: the sum over the four 16-lane rows, identical in all of them
+__device__ __forceinline__ double quad_sum(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    lo = __double2loint(v); hi = __double2hiint(v);
+    auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+// sum over the 16 lanes of each DPP row (identical inside the row)
+__device__ __forceinline__ double row_sum(double v) {
+    asm volatile("" : "+v"(v));
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row_max(double v) {
+    v = fmax(v, dpp_d<0xB1>(v));
+    v = fmax(v, dpp_d<0x4E>(v));
+    v = fmax(v, dpp_d<0x141>(v));
+    v = fmax(v, dpp_d<0x140>(v));
+    return v;
+}
+// a wave-uniform double, moved to a scalar register pair: the f64 arithmetic that produced it left it in VGPRs, where a
+// kernel-lifetime scalar (tolerances, mu, theta, ...) costs two registers of every lane -- or a scratch slot
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// whole-wave reductions: DPP inside the rows, then the four row results through SGPRs (wave-uniform result)
+__device__ __forceinline__ double wsum(double v) {
+    v = row_sum(v);
+    return uni((readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48)));
+}
+__device__ __forceinline__ double wmax(double v) {
+    v = row_max(v);
+    return uni(fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48))));
+}
+
+// Step J of the triangular inverse in the A-operand layout: Ws[s] += (Ws[s] of lane J of the row) * nl for the registers
+// s <= J / 4 (columns 4s + q <= J)
+template <int J>
+__device__ __forceinline__ void winv_step(double (&Ws)[4], double nl) {
+    asm volatile("s_nop 1\n\t"
+                 ".if 0 <= %5\n\tv_fmac_f64_dpp %0, %0, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 4 <= %5\n\tv_fmac_f64_dpp %1, %1, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 8 <= %5\n\tv_fmac_f64_dpp %2, %2, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 12 <= %5\n\tv_fmac_f64_dpp %3, %3, %4 row_newbcast:" DPP_STR(%5) " row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 : "+v"(Ws[0]), "+v"(Ws[1]), "+v"(Ws[2]), "+v"(Ws[3]) : "v"(nl), "n"(J));
+}
+
 // ---- batched LDS reads (see ipm_wreg.hip for the rest of the family) -------------------------------------------
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;

@@ -48,6 +48,12 @@ def unpack(packed, layout, names=("pobj", "dobj", "status", "iters", "y", "x")):
     return out
 
 
+# pycllp_hip_sparse_launch_info's `kernel` -> (variant, kernel family): 'wave' = the register-resident one-LP-per-wavefront
+# kernel (csrc/ipm_wreg.hip) on Gram term tables or on a dense image of A, 'block' = the one-LP-per-workgroup kernel of
+# csrc/ipm_block.inc (m <= 128), 'big' = the one-LP-per-workgroup kernel for large LPs (csrc/ipm_big.hip: 128 < m <= 256 or
+# 512 < n <= 1280), Gram from a term list or on the matrix cores
+SPARSE_KERNEL_KINDS = {0: ("block", "block"), 1: ("tables", "wave"), 2: ("dense image", "wave"),
+                       3: ("term list", "big"), 4: ("MFMA Gram", "big")}
 AUTOSCALE_BAND = (0.1, 10.0)
 
 
@@ -462,8 +468,7 @@ class HipDensePrimalNormalSolver(BaseSolver):
         d = dict(zip(("grid", "block", "lds_bytes", "m_pad", "n_pad"), [v.value for v in vals]))
         kind = _native.lib().pycllp_hip_dense_kernel_kind(self._handle)
         if kind >= 0:      # beyond the lane-group kernels: which of the sparse path's kernels served the last launch
-            d["variant"] = {0: "block", 1: "tables", 2: "dense image"}[kind]
-            d["kernel"] = "wave" if kind else "block"
+            d["variant"], d["kernel"] = SPARSE_KERNEL_KINDS[kind]
         return d
 
 
@@ -571,13 +576,10 @@ class HipSparsePrimalNormalSolver(HipDensePrimalNormalSolver):
         return dy.cpu().numpy()
 
     def launch_info(self):
-        """grid / block / LDS bytes of the last solve and which kernel ran it: 'wave' = the register-resident
-        one-LP-per-wavefront kernel (csrc/ipm_wreg.hip; 'variant': on Gram term 'tables' or on a 'dense image' of A), 'block' = the
-        one-LP-per-workgroup kernel (csrc/ipm_block.inc)."""
+        """grid / block / LDS bytes of the last solve and which kernel ran it (``SPARSE_KERNEL_KINDS``)."""
         vals = [ctypes.c_int() for _ in range(4)]
         _native.check(_native.lib().pycllp_hip_sparse_launch_info(self._handle, *[ctypes.byref(v) for v in vals]),
                       "pycllp_hip_sparse_launch_info")
         d = dict(zip(("grid", "block", "lds_bytes", "kernel"), [v.value for v in vals]))
-        d["variant"] = {0: "block", 1: "tables", 2: "dense image"}[d["kernel"]]
-        d["kernel"] = "wave" if d["kernel"] else "block"
+        d["variant"], d["kernel"] = SPARSE_KERNEL_KINDS[d["kernel"]]
         return d

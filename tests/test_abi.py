@@ -31,14 +31,14 @@ def test_defaults_and_argument_errors_without_gpu():
     o = _native.default_opts()
     assert (o.eps, o.delta, o.r, o.pivot_floor, o.refine_tol) == (1e-10, 0.02, 0.9, 1e-6, 1e-11)
     assert (o.max_iter, o.max_refine, o.flags) == (200, -1, 0)     # -1 = PYCLLP_MAX_REFINE_AUTO: 5 plain / 20 HSD, resolved in C
-    assert L.pycllp_hip_dense_max_rows() == 128 and L.pycllp_hip_dense_max_cols() == 512
+    assert L.pycllp_hip_dense_max_rows() == 256 and L.pycllp_hip_dense_max_cols() == 1280
     h = ctypes.c_void_p()
     # NULL matrix / bad sizes are rejected before any HIP call
     assert L.pycllp_hip_dense_init(3, 3, None, None, ctypes.byref(h)) == -1
     assert L.pycllp_hip_dense_init(0, 3, ctypes.c_void_p(8), None, ctypes.byref(h)) == -1
     assert b"bad argument" in L.pycllp_hip_last_error()
     # sizes outside the compiled kernels -> PYCLLP_E_UNSUPPORTED, surfaced as NotImplementedError
-    rc = L.pycllp_hip_dense_init(129, 40, ctypes.c_void_p(8), None, ctypes.byref(h))
+    rc = L.pycllp_hip_dense_init(257, 40, ctypes.c_void_p(8), None, ctypes.byref(h))
     assert rc == -2
     with pytest.raises(NotImplementedError):
         _native.check(rc, "init")
