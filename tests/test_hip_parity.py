@@ -314,12 +314,12 @@ def test_large_lps_on_the_workgroup_per_lp_kernel(case, hsd):
         x0 = rs.rand(B, n) + 0.1; y0 = rs.randn(B, m)
         b = x0 @ A.T; c = y0 @ A - (rs.rand(B, n) + 0.1)          # strictly feasible primal-dual pair, no identity columns
         lp = EqualityLP(SparseMatrix(matrix=A), b, c, 0.0)
-        name, variant = "hip_dense_primal_normal", "MFMA Gram"
+        name, variant = "hip_dense_primal_normal", None       # (half-dense: either Gram path may be the cheaper one)
     s = solver_registry[name](hsd=hsd)
     lp.init(s)
     st = lp.solve(s)
     info = s.launch_info()
-    assert info["kernel"] == "big" and info["variant"] == variant, info
+    assert info["kernel"] == "big" and variant in (None, info["variant"]), info
     r = oracle_on(lp, flags=32 if hsd else 0)
     np.testing.assert_array_equal(st, r["status"])
     assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
