@@ -49,7 +49,8 @@ typedef struct oracle_opts {
     int max_refine;     /* refinement passes           (ldl.cl:645)                */
     int flags;          /* bit0: warm start (x,z,y are in/out, primal_normal.cl:213-219);
                            bit3 (8): autoscale -- solve with b/max|b|, c/max|c| and scale the results back;
-                           bit5 (32): homogeneous self-dual embedding, see hsd_one_raw() */
+                           bit5 (32): homogeneous self-dual embedding, see hsd_one_raw();
+                           bit7 (128): Mehrotra predictor-corrector on the plain path, see ipm_one_pc() */
 } oracle_opts;
 
 void oracle_default_opts(oracle_opts *o) {
@@ -258,11 +259,16 @@ static int hsd_one_raw(int m, int N, const double *A, const double *b, const dou
                        double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
                        work *wk);
 
+static int ipm_one_pc(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                      double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                      work *wk);
+
 static int ipm_one_raw(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
                        double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
                        work *wk) {
-    return (o->flags & 32) ? hsd_one_raw(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk)
-                           : ipm_one_path(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+    if (o->flags & 32) return hsd_one_raw(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+    if (o->flags & 128) return ipm_one_pc(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
+    return ipm_one_path(m, N, A, b, c, x, y, z, pobj, dobj, iters, nrefs, o, wk);
 }
 
 /* wrapper implementing the optional scaling (not in the reference): b/max|b|, c/max|c| */
@@ -358,6 +364,143 @@ static int ipm_one_path(int m, int N, const double *A, const double *b, const do
         normr0 = normr;
         norms0 = norms;
     }
+    *pobj = po;
+    *dobj = du;
+    *iters = it;
+    if (nrefs) *nrefs = totref;
+    return stat;
+}
+
+/*
+ * Predictor-corrector variant of the same path (flag 128, PYCLLP_FLAG_PREDCORR; not in the reference's OpenCL kernel).
+ * The reference's CPU solver alternates a pure predictor iteration (delta = 0) with a pure centering one (delta = 1),
+ * each with its own factorisation (ipo/hsd.c:133-143, 222-260); Mehrotra's rule does both with ONE factorisation per
+ * iteration -- the second solve costs a forward/back substitution, not a factorisation:
+ *   predictor (mu = 0):  M dy_a = A(d t_a) - rho, t_a = c - A'y;  dx_a = d (t_a - A'dy_a);  dz_a = -z - z dx_a / x
+ *   theta_a = min(1, 1 / max(-dx_a/x, -dz_a/z));  gamma_a = (x + theta_a dx_a)'(z + theta_a dz_a)
+ *   centering from the predictor's success:  sigma = (gamma_a / gamma)^3,  mu = sigma gamma / N
+ *   corrector:  t = t_a + (mu - dx_a dz_a) / x;  M dy = A(d t) - rho;  dx = d (t - A'dy)  (+ the x-space refinement of
+ *   newton_dy);  dz = (mu - dx_a dz_a - z dx) / x - z;  step theta = min(r / max(-dx/x, -dz/z), 1) as on the plain path.
+ * Everything else (start, stop tests, statuses, growth exits, objectives) is ipm_one_path's.
+ */
+static int ipm_one_pc(int m, int N, const double *A, const double *b, const double *c, double *x, double *y,
+                      double *z, double *pobj, double *dobj, int *iters, int *nrefs, const oracle_opts *o,
+                      work *wk) {
+    int stat = 5;
+    if (!(o->flags & 1)) {
+        for (int j = 0; j < N; j++) { x[j] = 1.0; z[j] = 1.0; }
+        for (int i = 0; i < m; i++) y[i] = 1.0;
+    }
+    double nb = 0.0, nc = 0.0;
+    for (int i = 0; i < m; i++) nb += b[i] * b[i];
+    for (int j = 0; j < N; j++) nc += c[j] * c[j];
+    const double tol_r = o->eps * (1.0 + sqrt(nb));
+    const double tol_s = o->eps * (1.0 + sqrt(nc));
+    const double etol = o->refine_tol * (1.0 + sqrt(nb));
+    double normr0 = 1e300, norms0 = 1e300;
+    int it, totref = 0;
+    double po = 0.0, du = 0.0;
+    double *d = wk->d, *t = wk->t, *dx = wk->w, *dz = wk->sigma;
+    double *cor = (double *)malloc(sizeof(double) * N), *aty = (double *)malloc(sizeof(double) * N);
+    for (it = 0; it < o->max_iter; it++) {
+        double normr = 0.0, norms = 0.0, gamma = 0.0;
+        for (int i = 0; i < m; i++) {
+            double rho = b[i];
+            for (int j = 0; j < N; j++) rho -= A[i * N + j] * x[j];
+            wk->rho[i] = rho;
+            normr += rho * rho;
+        }
+        normr = sqrt(normr);
+        po = 0.0; du = 0.0;
+        for (int j = 0; j < N; j++) {
+            double a = 0.0;
+            for (int i = 0; i < m; i++) a += A[i * N + j] * y[i];
+            aty[j] = a;
+            const double sigma = c[j] - a + z[j];
+            norms += sigma * sigma;
+            gamma += z[j] * x[j];
+            po += c[j] * x[j];
+        }
+        norms = sqrt(norms);
+        for (int i = 0; i < m; i++) du += b[i] * y[i];
+        if (!(isfinite(normr) && isfinite(norms) && isfinite(gamma))) { stat = 3; break; }
+        if (normr <= tol_r && norms <= tol_s && gamma <= o->eps * (1.0 + fabs(po))) { stat = 0; break; }
+        if (normr > 10 * normr0 && normr > 1e3 * tol_r) { stat = 2; break; }
+        if (norms > 10 * norms0 && norms > 1e3 * tol_s) { stat = 4; break; }
+
+        for (int k = 0; k < N; k++) { d[k] = x[k] / z[k]; t[k] = c[k] - aty[k]; }
+        gram(m, N, A, d, wk->M);
+        factor(m, wk->M, wk->L, wk->D, o->pivot_floor, 0.0);
+        /* predictor */
+        for (int i = 0; i < m; i++) {
+            double adt = 0.0;
+            for (int k = 0; k < N; k++) adt += A[i * N + k] * d[k] * t[k];
+            wk->S[i] = adt - wk->rho[i];
+        }
+        oracle_forward_backward(m, wk->L, wk->D, wk->S);
+        double tha = 0.0;
+        for (int k = 0; k < N; k++) {
+            double atdy = 0.0;
+            for (int i = 0; i < m; i++) atdy += A[i * N + k] * wk->S[i];
+            const double dxa = (t[k] - atdy) * d[k];
+            const double dza = -z[k] - z[k] * dxa / x[k];
+            dx[k] = dxa; dz[k] = dza;
+            tha = fmax(tha, fmax(-dza / z[k], -dxa / x[k]));
+        }
+        tha = fmin(1.0 / tha, 1.0);      /* (tha = 0: 1/0 = inf -> 1) */
+        double ga = 0.0;
+        for (int k = 0; k < N; k++) ga += (x[k] + tha * dx[k]) * (z[k] + tha * dz[k]);
+        const double sg = ga / gamma;
+        const double mu = sg * sg * sg * gamma / N;
+        /* corrector */
+        for (int k = 0; k < N; k++) { cor[k] = mu - dx[k] * dz[k]; t[k] = t[k] + cor[k] / x[k]; }
+        for (int i = 0; i < m; i++) {
+            double adt = 0.0;
+            for (int k = 0; k < N; k++) adt += A[i * N + k] * d[k] * t[k];
+            wk->S[i] = adt - wk->rho[i];
+        }
+        oracle_forward_backward(m, wk->L, wk->D, wk->S);
+        for (int i = 0; i < m; i++) wk->dy[i] = wk->S[i];
+        for (int k = 0; k < N; k++) {
+            double atdy = 0.0;
+            for (int i = 0; i < m; i++) atdy += A[i * N + k] * wk->dy[i];
+            dx[k] = (t[k] - atdy) * d[k];
+        }
+        int nref = 0;
+        for (;;) {
+            double maxe = 0.0;
+            for (int i = 0; i < m; i++) {
+                double adx = 0.0;
+                for (int k = 0; k < N; k++) adx += A[i * N + k] * dx[k];
+                wk->S[i] = wk->rho[i] - adx;
+                maxe = fmax(maxe, fabs(wk->S[i]));
+            }
+            if (!(maxe > etol) || nref >= o->max_refine) break;
+            oracle_forward_backward(m, wk->L, wk->D, wk->S);
+            for (int i = 0; i < m; i++) wk->dy[i] -= wk->S[i];
+            for (int k = 0; k < N; k++) {
+                double ate = 0.0;
+                for (int i = 0; i < m; i++) ate += A[i * N + k] * wk->S[i];
+                dx[k] += d[k] * ate;
+            }
+            nref++;
+        }
+        totref += nref;
+        int bad = 0;
+        for (int i = 0; i < m; i++) if (!isfinite(wk->dy[i])) bad = 1;
+        if (bad) { stat = 3; break; }
+        double theta = 0.0;
+        for (int j = 0; j < N; j++) {
+            dz[j] = (cor[j] - z[j] * dx[j]) / x[j] - z[j];
+            theta = fmax(theta, fmax(-dz[j] / z[j], -dx[j] / x[j]));
+        }
+        theta = fmin(o->r / theta, 1.0);
+        for (int i = 0; i < m; i++) y[i] += theta * wk->dy[i];
+        for (int j = 0; j < N; j++) { z[j] += theta * dz[j]; x[j] += theta * dx[j]; }
+        normr0 = normr;
+        norms0 = norms;
+    }
+    free(cor); free(aty);
     *pobj = po;
     *dobj = du;
     *iters = it;

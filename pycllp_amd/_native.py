@@ -25,6 +25,7 @@ STATUS_OPTIMAL, STATUS_PRIMAL_INFEASIBLE, STATUS_NUMERICAL, STATUS_DUAL_INFEASIB
 FLAG_WARM_START, FLAG_WAVE_KERNEL, FLAG_FORCE_GUARD_PATH, FLAG_AUTOSCALE, FLAG_NO_SLACK_PATH = 1, 2, 4, 8, 16
 FLAG_HSD = 32
 FLAG_BLOCK_KERNEL = 64
+FLAG_PREDCORR = 128
 
 
 class Opts(ctypes.Structure):

@@ -103,6 +103,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
     const bool warm = nwt || (o.flags & PYCLLP_FLAG_WARM_START) != 0;
     const bool autoscale = !nwt && (o.flags & PYCLLP_FLAG_AUTOSCALE) != 0;
     const bool hsd = !nwt && (o.flags & PYCLLP_FLAG_HSD) != 0;
+    const bool pc = !nwt && !hsd && (o.flags & PYCLLP_FLAG_PREDCORR) != 0;   // Mehrotra's predictor-corrector (oracle ipm_one_pc)
     const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
     const double nm = (double)(n + m);
 
@@ -385,7 +386,8 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             const double norms = sqrt(bsum(s2, red, tid));
             gam = bsum(gam, red, tid); po = bsum(pp, red, tid); du = bsum(dd, red, tid);
             const double normr = sqrt(bsum(rho_i * rho_i, red, tid));
-            const double mu = nwt ? nwt_mu : (hsd ? o.delta * (gam + tau * kap) / (double)(n + 1) : o.delta * gam / nm);
+            // (predictor-corrector: 0 for the predictor, set from its outcome below)
+            double mu = nwt ? nwt_mu : (hsd ? o.delta * (gam + tau * kap) / (double)(n + 1) : (pc ? 0.0 : o.delta * gam / nm));
             const double phi = du - po + kap;
             if (!nwt) {
                 if (hsd) {      // oracle hsd_one_raw: optimal, or a primal / dual ray
@@ -445,7 +447,9 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             const bool viol = factor(beta2, hsd ? 0.0 : o.pivot_floor, hsd);
             if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = PYCLLP_STATUS_NUMERICAL; break; }
 
-            double dx[BNC], w2[BNC];
+            double dx[BNC], w2[BNC], cor[BNC];
+#pragma unroll
+            for (int k = 0; k < BNC; k++) cor[k] = mu;        // (plain path: the complementarity target is mu itself)
             double dtau = 0.0, etol_it = etol, rhot_i = rho_i;
             int nref = 0;
             if (hsd) {
@@ -475,6 +479,37 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                 for (int k = 0; k < BNC; k++) dx[k] = fma(d[k] * uu[k], dtau, dx[k]);
                 etol_it = o.refine_tol * (1.0 + nbn) * fmax(tau, kap);
             } else {
+                if (pc) {
+                    // predictor (mu = 0) -> how far it gets -> centering -> the corrector's target and right-hand side
+                    solve();
+                    At_cols(um, w2);
+                    double dxa[BNC], dza[BNC], tha = 0.0;
+#pragma unroll
+                    for (int k = 0; k < BNC; k++) {
+                        dxa[k] = (t[k] - w2[k]) * d[k];
+                        dza[k] = ok[k] ? -z[k] - z[k] * dxa[k] / x[k] : 0.0;
+                        if (ok[k]) tha = fmax(tha, fmax(-dza[k] / z[k], -dxa[k] / x[k]));
+                    }
+                    tha = bmax(tha, red, tid);
+                    const double theta_a = fmin(1.0 / tha, 1.0);
+                    double ga = 0.0;
+#pragma unroll
+                    for (int k = 0; k < BNC; k++) ga += ok[k] ? fma(theta_a, dxa[k], x[k]) * fma(theta_a, dza[k], z[k]) : 0.0;
+                    ga = bsum(ga, red, tid);
+                    const double sgm = ga / gam;
+                    mu = sgm * sgm * sgm * gam / (double)n;
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < BNC; k++) {
+                        const int j = tid + BT * k;
+                        cor[k] = ok[k] ? mu - dxa[k] * dza[k] : 0.0;
+                        t[k] = ok[k] ? t[k] + cor[k] / x[k] : 0.0;
+                        if (j < NPv) vx[j] = d[k] * t[k];
+                    }
+                    __syncthreads();
+                    const double adt2 = A_row(vx);
+                    if (tid < MP) um[tid] = (tid < m) ? adt2 - rho_i : 0.0;
+                }
                 solve();
                 if (tid < MP) dyv[tid] = um[tid];
                 At_cols(um, w2);
@@ -510,7 +545,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             double dz[BNC], th = hsd ? fmax(fmax(-dtau / tau, -dkap / kap), 0.0) : 0.0;
 #pragma unroll
             for (int k = 0; k < BNC; k++) {
-                dz[k] = ok[k] ? (mu - z[k] * dx[k]) / x[k] - z[k] : 0.0;
+                dz[k] = ok[k] ? (cor[k] - z[k] * dx[k]) / x[k] - z[k] : 0.0;
                 if (ok[k]) th = fmax(th, fmax(-dz[k] / z[k], -dx[k] / x[k]));
             }
             th = bmax(th, red, tid);

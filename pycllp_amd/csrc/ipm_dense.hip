@@ -668,7 +668,7 @@ static hipError_t launch_solve(pycllp_hip_dense* h, long B, const double* b, con
 #define FIRST_GEN_SOLVE(MP, NP) nullptr
 #endif
 
-template <int MP, int NP, bool SL, bool HSD = false>
+template <int MP, int NP, bool SL, bool HSD = false, bool PC = false>
 static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* b, const double* c, double* x, double* y,
                                      double* z, double* pobj, double* dobj, int* status, int* iters, DevOpts o,
                                      hipStream_t st) {
@@ -683,7 +683,7 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     const LaunchPlan p{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
-    auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL>;
+    auto kernel = HSD ? hsd_group_kernel<MP, NP, SL> : ipm_group_kernel<MP, NP, SL, PC>;
     hipError_t e = set_dyn_lds((const void*)kernel, p.lds);
     if (e != hipSuccess) return e;
     int* qhead = nullptr; unsigned slot = 0;
@@ -715,12 +715,13 @@ struct Variant {
     solve_launch_fn solve;        // wave-per-LP kernel (first generation)
     solve_launch_fn solve_group;  // group-per-LP kernel (default)
     solve_launch_fn solve_hsd;    // group-per-LP kernel on the homogeneous self-dual embedding (PYCLLP_FLAG_HSD)
+    solve_launch_fn solve_pc;     // group-per-LP kernel with Mehrotra's predictor-corrector (PYCLLP_FLAG_PREDCORR)
     newton_launch_fn newton;
 };
 
 #define VARIANT(MP, NP) \
     { MP, NP, Geo<MP, NP>::APACK, launch_pack<MP, NP>, FIRST_GEN_SOLVE(MP, NP), launch_solve_group<MP, NP, false>, \
-      launch_solve_group<MP, NP, false, true>, launch_newton<MP, NP> }
+      launch_solve_group<MP, NP, false, true>, launch_solve_group<MP, NP, false, false, true>, launch_newton<MP, NP> }
 
 // ordered by cost: the first variant that covers (m, n) is used
 static const Variant kVariants[] = {
@@ -730,8 +731,9 @@ static const Variant kVariants[] = {
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 // slack-aware group kernels: (MP, NP) with NP - MP padded dense columns + the m identity columns
-struct SlackVariant { int mp, np; solve_launch_fn solve_group, solve_hsd; };
-#define SLACK_VARIANT(MP, NP) { MP, NP, launch_solve_group<MP, NP, true>, launch_solve_group<MP, NP, true, true> }
+struct SlackVariant { int mp, np; solve_launch_fn solve_group, solve_hsd, solve_pc; };
+#define SLACK_VARIANT(MP, NP) { MP, NP, launch_solve_group<MP, NP, true>, launch_solve_group<MP, NP, true, true>, \
+                                launch_solve_group<MP, NP, true, false, true> }
 static const SlackVariant kSlackVariants[] = {
     SLACK_VARIANT(16, 32), SLACK_VARIANT(16, 48), SLACK_VARIANT(16, 64), SLACK_VARIANT(32, 64),
     SLACK_VARIANT(32, 96), SLACK_VARIANT(32, 128),
@@ -917,15 +919,17 @@ int pycllp_hip_dense_solve(pycllp_hip_dense* h, long B, const double* b_dev, con
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_AUTOSCALE is not available with PYCLLP_FLAG_WAVE_KERNEL");
     if ((o.flags & PYCLLP_FLAG_HSD) && (o.flags & PYCLLP_FLAG_WAVE_KERNEL))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_HSD is not available with PYCLLP_FLAG_WAVE_KERNEL");
+    if ((o.flags & PYCLLP_FLAG_PREDCORR) && (o.flags & (PYCLLP_FLAG_HSD | PYCLLP_FLAG_WAVE_KERNEL)))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_dense_solve: PYCLLP_FLAG_PREDCORR is an option of the reference's path (not with PYCLLP_FLAG_HSD)");
     const Variant& v = kVariants[h->variant];
-    const bool hsd = (o.flags & PYCLLP_FLAG_HSD) != 0;
-    solve_launch_fn fn = hsd ? v.solve_hsd : v.solve_group;
+    const bool hsd = (o.flags & PYCLLP_FLAG_HSD) != 0, pc = (o.flags & PYCLLP_FLAG_PREDCORR) != 0;
+    solve_launch_fn fn = hsd ? v.solve_hsd : (pc ? v.solve_pc : v.solve_group);
     if (o.flags & PYCLLP_FLAG_WAVE_KERNEL) {
         fn = v.solve;
         if (!fn) return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_dense_solve: the first-generation kernel (PYCLLP_FLAG_WAVE_KERNEL) is not "
                                                       "part of this build (diagnostic builds: make EXTRA=-DPYCLLP_FIRST_GEN)");
     } else if (h->variant_sl >= 0 && !(o.flags & PYCLLP_FLAG_NO_SLACK_PATH))
-        fn = hsd ? kSlackVariants[h->variant_sl].solve_hsd : kSlackVariants[h->variant_sl].solve_group;
+        fn = hsd ? kSlackVariants[h->variant_sl].solve_hsd : (pc ? kSlackVariants[h->variant_sl].solve_pc : kSlackVariants[h->variant_sl].solve_group);
     hipError_t e = fn(h, B, b_dev, c_dev, x_dev, y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, o,
                       (hipStream_t)stream);
     if (e != hipSuccess) return set_err((int)e, "solve kernel launch");
@@ -1137,6 +1141,12 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     return 0;
 }
 
+// which kernels of the sparse path implement the predictor-corrector step
+static bool sparse_predcorr_available(const pycllp_hip_sparse* h, bool per_problem_a, int flags) {
+    (void)per_problem_a; (void)flags;
+    return h->big != nullptr;
+}
+
 static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch, const double* b_dev, const double* c_dev,
                              double* x_dev, double* y_dev, double* z_dev, double* pobj_dev, double* dobj_dev, int* status_dev,
                              int* iters_dev, const pycllp_hip_opts* opts, void* stream) {
@@ -1147,6 +1157,10 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     if ((o.flags & PYCLLP_FLAG_WARM_START) && (!y_dev || !z_dev))
         return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: warm start needs y_dev and z_dev");
     hipStream_t st = (hipStream_t)stream;
+    if ((o.flags & PYCLLP_FLAG_PREDCORR) && (o.flags & PYCLLP_FLAG_HSD))
+        return set_err(PYCLLP_E_BADARG, "pycllp_hip_sparse_solve: PYCLLP_FLAG_PREDCORR is an option of the reference's path (not with PYCLLP_FLAG_HSD)");
+    if ((o.flags & PYCLLP_FLAG_PREDCORR) && !sparse_predcorr_available(h, a_batch != nullptr, o.flags))
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve: PYCLLP_FLAG_PREDCORR is not available on the kernel that serves this LP");
     if (h->big) {
         if (a_batch) return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values of A stop at m = 128, n = 512");
         int* qb = nullptr; unsigned sb_ = 0; int grid_b = 0;

@@ -560,6 +560,53 @@ def test_alternative_kernel_paths_agree_with_oracle(flags, what, m, n):
     assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
 
 
+# ---- Mehrotra predictor-corrector (PYCLLP_FLAG_PREDCORR) ---------------------------------------------
+
+@pytest.mark.parametrize("m,n", [(16, 32), (32, 64)])
+@pytest.mark.parametrize("extra", [0, 16, 8])
+def test_predictor_corrector_on_baseline_configs(m, n, extra):
+    """predcorr=True: one factorisation, two solves per iteration (oracle ipm_one_pc; the reference's CPU solver alternates
+    predictor and centering iterations instead, ipo/hsd.c:133-143, 222-260).  Same optimum as the reference solver's
+    goldens to 1e-8, LP by LP the oracle's iterations (+-1) and objectives (1e-9), ~27 % fewer iterations than the
+    reference's rule at its own step fraction.  extra: 16 = generic (not slack-aware) kernel, 8 = autoscale."""
+    g = golden("config_%dx%d.npz" % (m, n))
+    A, b, c = problems.random_dense_arrays(m, n, int(g["nobj"]), seed=0)
+    elp, s = solve_arrays(A, b, c, predcorr=True, hsd=False, flags=extra)
+    assert (s.status == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    r = oracle_on(elp, auto=False, flags=128 | (extra & 8))
+    np.testing.assert_array_equal(s.status, r["status"])
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1 and (s.iters == r["iters"]).mean() > 0.98
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    plain = oracle_on(elp, auto=False, flags=extra & 8)
+    assert s.iters.mean() < 0.8 * plain["iters"].mean()
+    if extra == 0:      # a longer step fraction pays more with the corrector: r = 0.99
+        elp, s2 = solve_arrays(A[:, :], b[:512], c[:512], predcorr=True, hsd=False, r=0.99)
+        assert (s2.status == 0).all() and s2.iters.mean() < 0.6 * plain["iters"].mean()
+        assert rel_err(s2.primal_obj, g["pobj"][:512]).max() < OBJ_TOL
+
+
+def test_predictor_corrector_options_and_large_lps():
+    """The option through the default plugin (hsd='auto': what does not end optimal is re-solved on the embedding), on the
+    large-LP kernel, and where it is refused: with hsd=True."""
+    for A, b, c, ref_status, highs, ref_pobj in status_cases()[:3]:
+        elp, s = solve_arrays(A, b, c, predcorr=True)
+        np.testing.assert_array_equal(s.status, highs)
+        check_certificates(elp.A.todense(), elp.b, elp.c, dict(status=s.status, x=s.x, y=s.y, z=s.z))
+    with pytest.raises(ValueError):
+        solver_registry["hip_dense_primal_normal"](predcorr=True, hsd=True)
+    A, b, c = problems.random_dense_arrays(150, 120, 10, seed=3)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_dense_primal_normal"](predcorr=True, hsd=False)
+    lp.init(s)
+    st = lp.solve(s)
+    assert s.launch_info()["kernel"] == "big" and (st == 0).all()
+    r = oracle_on(lp, flags=128)
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    assert s.iters.mean() < 0.8 * oracle_on(lp)["iters"].mean()
+
+
 # ---- homogeneous self-dual embedding (PYCLLP_FLAG_HSD, SURVEY 8f-3) -----------------------------------------------------
 
 def test_hsd_statuses_against_reference_highs_and_oracle():
