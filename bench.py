@@ -134,12 +134,13 @@ class Workload(object):
     """One synthetic batch resident on the device + the solver that runs it.  Everything the JSON record of a workload
     needs is derived here, so that the headline and the secondary records are built by the same code."""
 
-    def __init__(self, name, B, rank, dev, reserve=0, hsd=False):
+    def __init__(self, name, B, rank, dev, reserve=0, hsd=False, predcorr=False):
         import torch
         from pycllp_amd import problems
         from pycllp_amd.lp import SparseMatrix, EqualityLP, StandardLP
         from pycllp_amd.solvers import solver_registry
         self.name, self.B, self.hsd, self.dev = name, B, bool(hsd), dev
+        self.predcorr = bool(predcorr)      # PYCLLP_FLAG_PREDCORR: Mehrotra's predictor-corrector (an option, never the headline)
         self.per_a = name == "perA"
         self.sparse = name in ("sparse5", "perA")
         self.a_values = None
@@ -159,22 +160,26 @@ class Workload(object):
                 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
             # hsd=False: the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto'
             # runs first; hsd=True: the homogeneous self-dual variant (41 instead of 52 iterations, two solves per iteration)
-            solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=self.hsd, reserve_cus=reserve)
+            solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve)
             self.what = ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 non-zeros) "
                          "-> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)%s"
                          % (B, m_, n_, n_ + m_, "; PER-PROBLEM VALUES of A on that structure (SURVEY 8f-4; shared x U[0.75,1.25))"
                             if self.per_a else ""))
+            if self.predcorr:
+                self.what += "; OPTION predcorr=True (Mehrotra predictor-corrector: one factorisation, two solves per iteration)"
         else:
             m_, n_ = {"dense3": (M, N_STD), "dense2": (16, 32), "dense100": (100, 80)}[name]
             A, b, c = problems.random_dense_arrays(m_, n_, B, seed=0, shard=rank)
             Ae, be, ce = problems.equality_arrays(A, b, c)
             lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
-            solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, reserve_cus=reserve)
+            solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve)
             cfg = {"dense3": "BASELINE.json configs[2]", "dense2": "BASELINE.json configs[1]",
                    "dense100": "a dense LP beyond the lane-group kernels; m = 100 is the reference's own kernel-test size, "
                                "tests/test_ldl.py:226-238"}[name]
             self.what = ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, A~U[0,1) shared, "
                          "b,c~U[0.5,1.5), seed 0 (%s)" % (B, m_, n_, n_ + m_, cfg))
+            if self.predcorr:
+                self.what += "; OPTION predcorr=True (Mehrotra predictor-corrector: one factorisation, two solves per iteration)"
         self.m, self.n, self.N = m_, n_, n_ + m_
         self.A, self.b_std, self.c_std = A, b, c
         self.lp, self.solver = lp, solver
@@ -243,6 +248,9 @@ class Workload(object):
             # executed work: the slack-aware kernels (lane-group kernel and the dense-image wave kernel alike) run the Gram
             # product and the mat-vecs on the n = N - m dense columns only (the identity columns of [A | I] bypass them)
             f_exec = iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
+        if self.predcorr:      # + one forward/back substitution (4 m^2) and A'u, A v (4 nnz resp. 4 m n) per iteration
+            extra = iters_mean * (4 * m_ * m_ + (4 * (int(self.A.nnz) + m_) if self.sparse else 4 * m_ * n_))
+            f_alg += extra; f_exec += extra
         t = kern_ms * 1e-3
         tf_alg, tf_exec = f_alg * B / t / 1e12, f_exec * B / t / 1e12
         a_bytes = 8 * (int(self.A.nnz) + m_) if self.per_a else 0   # per-problem A: every LP reads its own values (equality form)
@@ -254,7 +262,7 @@ class Workload(object):
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
-            ent = json.load(open(tpath)).get(self.name + ("_hsd" if self.hsd else ""))
+            ent = json.load(open(tpath)).get(self.name + ("_hsd" if self.hsd else "") + ("_predcorr" if self.predcorr else ""))
             if ent and ent.get("lps_per_launch") == B and world == 1:
                 traffic, traffic_src = ent.get("bytes_per_launch"), ent.get("source")
         return {"bound": "mfma", "achieved": tf_exec, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -274,11 +282,13 @@ class Workload(object):
             if info.get("kernel") == "wave":
                 return ("%s (one LP per wavefront, factor in registers, A as %s)%s, grid %d x block %d, %d B LDS"
                         % ("hsd_wreg_kernel" if self.hsd else "ipm_wreg_kernel", info.get("variant", "tables"),
-                           ", PYCLLP_FLAG_HSD" if self.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
+                           ", PYCLLP_FLAG_HSD" if self.hsd else (", PYCLLP_FLAG_PREDCORR" if self.predcorr else ""),
+                           info["grid"], info["block"], info["lds_bytes"]))
             return ("ipm_block_kernel (one LP per 256-thread workgroup)%s, grid %d x block %d, %d B LDS"
                     % (", PYCLLP_FLAG_HSD" if self.hsd else "", info["grid"], info["block"], info["lds_bytes"]))
-        return ("%s<%d,%d> grid %d x block %d, %d B LDS" % ("hsd_group_kernel" if self.hsd else "ipm_group_kernel",
-                                                            info["m_pad"], info["n_pad"], info["grid"], info["block"], info["lds_bytes"]))
+        return ("%s<%d,%d%s> grid %d x block %d, %d B LDS" % ("hsd_group_kernel" if self.hsd else "ipm_group_kernel",
+                                                              info["m_pad"], info["n_pad"], ",predictor-corrector" if self.predcorr else "",
+                                                              info["grid"], info["block"], info["lds_bytes"]))
 
     def launch_info(self):
         return self.solver.launch_info()
@@ -294,12 +304,12 @@ class Workload(object):
                              chunk=256 if self.m <= 32 else 16)
 
 
-def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None):
+def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None, predcorr=False):
     """One secondary record: the workload resident in HBM, `warmup` untimed and `steps` timed passes (HIP events around
     every launch on the launch stream, wall clock between two device synchronisations), parity, roofline, CPU reference."""
     import torch
     t_build = time.perf_counter()
-    w = Workload(name, B, 0, dev, hsd=hsd)
+    w = Workload(name, B, 0, dev, hsd=hsd, predcorr=predcorr)
     for k in range(warmup):
         w.step(k % 2)
     torch.cuda.synchronize(dev)
@@ -315,7 +325,7 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
     info = w.launch_info()
     status = buf["status"].cpu().numpy(); iters = buf["iters"].cpu().numpy()
     pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
-    rec = {"workload": name + ("_hsd" if hsd else ""), "value": B * steps / elapsed, "unit": "LPs/s", "steps": steps,
+    rec = {"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if predcorr else ""), "value": B * steps / elapsed, "unit": "LPs/s", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kern_ms,
            "config": {"workload": w.what, "lps_per_gpu": B, "m": w.m, "n": w.n, "N_equality": w.N, "kernel": w.kernel_name(info)},
            "solved_optimal": int((status == 0).sum()), "mean_ipm_iterations": float(iters.mean()),
@@ -326,8 +336,10 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
     return rec
 
 
-SECONDARY = (("dense2", 4096, False), ("sparse5", 16384, False), ("sparse5", 16384, True), ("perA", 16384, False),
-             ("dense100", 16384, False))
+# (workload, LPs, hsd, predcorr)
+SECONDARY = (("dense2", 4096, False, False), ("sparse5", 16384, False, False), ("sparse5", 16384, True, False),
+             ("perA", 16384, False, False), ("dense100", 16384, False, False),
+             ("dense3", 65536, False, True), ("sparse5", 16384, False, True))
 
 
 def main():
@@ -339,6 +351,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline record only (no `secondary` list)")
     ap.add_argument("--hsd", action="store_true", help="time the homogeneous self-dual variant (PYCLLP_FLAG_HSD) of --workload")
+    ap.add_argument("--predcorr", action="store_true", help="time the predictor-corrector option (PYCLLP_FLAG_PREDCORR) of --workload")
     ap.add_argument("--workload", choices=("dense3", "sparse5", "perA", "dense2", "dense100"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal; perA: "
@@ -392,7 +405,7 @@ def main():
     B = args.batch
     if args.batch == B_PER_GPU and args.workload != "dense3":
         B = 4096 if args.workload == "dense2" else 16384
-    wl = Workload(args.workload, B, rank, dev, reserve=reserve, hsd=args.hsd)
+    wl = Workload(args.workload, B, rank, dev, reserve=reserve, hsd=args.hsd, predcorr=args.predcorr)
     solver, bd, cd, Nn = wl.solver, wl.bd, wl.cd, wl.N
     sparse, per_a, m_, n_ = wl.sparse, wl.per_a, wl.m, wl.n
 
@@ -491,20 +504,23 @@ def main():
             "cpu_baseline": cpu,
             "cpu_port": cpu_all,
         }
-        if world == 1 and not multi and args.workload == "dense3" and not args.hsd and not args.no_secondary and B == B_PER_GPU:
+        if (world == 1 and not multi and args.workload == "dense3" and not args.hsd and not args.predcorr and not args.no_secondary
+                and B == B_PER_GPU):
             # the other single-GPU configurations under the same clock (records; `value` above stays the headline's)
             del wl
             sec, cpu5 = [], None
-            for name, Bs, hsd in SECONDARY:
+            for name, Bs, hsd, pc in SECONDARY:
                 try:
-                    reuse = cpu5 if (name == "sparse5" and hsd) else None     # same LPs, same reference solver: timed once
-                    r = measure_secondary(name, Bs, dev, steps=5, warmup=2, hsd=hsd,
+                    # same LPs, same reference solver: timed once (the headline's own CPU leg serves dense3_predcorr)
+                    reuse = cpu5 if (name == "sparse5" and (hsd or pc)) else (cpu if name == "dense3" else None)
+                    r = measure_secondary(name, Bs, dev, steps=5, warmup=2, hsd=hsd, predcorr=pc,
                                           cpu_seconds=None if args.no_cpu_baseline else 4.0, cpu_from=reuse)
-                    if name == "sparse5" and not hsd:
+                    if name == "sparse5" and not hsd and not pc:
                         cpu5 = r["cpu_baseline"]
                     sec.append(r)
                 except Exception as exc:      # a secondary record must never cost the headline its line
-                    sec.append({"workload": name + ("_hsd" if hsd else ""), "error": "%s: %s" % (type(exc).__name__, exc)})
+                    sec.append({"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if pc else ""),
+                                "error": "%s: %s" % (type(exc).__name__, exc)})
             out["secondary"] = sec
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

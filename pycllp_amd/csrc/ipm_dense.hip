@@ -1143,8 +1143,8 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
 
 // which kernels of the sparse path implement the predictor-corrector step
 static bool sparse_predcorr_available(const pycllp_hip_sparse* h, bool per_problem_a, int flags) {
-    (void)per_problem_a; (void)flags;
-    return h->big != nullptr;
+    if (h->big) return true;
+    return !per_problem_a && !(flags & PYCLLP_FLAG_BLOCK_KERNEL) && wreg_has_predcorr(h->wreg) != 0;
 }
 
 static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch, const double* b_dev, const double* c_dev,

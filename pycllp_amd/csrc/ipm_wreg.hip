@@ -1006,11 +1006,12 @@ __device__ __forceinline__ void wreg_setup(WReg<MB, NQ, DA, PA>& w, const WregTa
 // TCV: the caller has parked x and z in the stage (at NP, 2 NP) and cv = c - A'y in vd_() in place of d; t = cv + mu / x and
 // d = x / z are formed here (the same expressions the caller used for the right-hand side).
 // Out: dy (per row), dx, wv = A'dy, e = rho - A dx.  Returns the refinement passes used; `bad` reports a non-finite dy.
-template <bool TCV, int MB, int NQ, bool DA, bool PA>
+// COR (predictor-corrector): the complementarity target of column j is cor[j] (= mu - dx_a dz_a) instead of the scalar mu.
+template <bool TCV, bool COR = false, int MB, int NQ, bool DA, bool PA>
 __device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA, PA>& w, const bool (&okc)[NQ], const bool (&okr)[WGeo<MB>::MR],
                                             const double (&rho)[WGeo<MB>::MR], double etol, int max_refine, double mu,
                                             double (&dy)[WGeo<MB>::MR], double (&dx)[NQ], double (&wv)[NQ],
-                                            double (&e)[WGeo<MB>::MR], bool& bad STAMP_ARGS) {
+                                            double (&e)[WGeo<MB>::MR], bool& bad, const double* cor STAMP_ARGS) {
     constexpr int MR = WGeo<MB>::MR, MP = WGeo<MB>::MP;
     const int& lane = w.lane;
     double* vx = w.stage_();
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ int newton_solve(WReg<MB, NQ, DA, PA>& w, const bool 
 #pragma unroll
             for (int qq = 0; qq < NQ; qq++) {
                 double tq;
-                if (TCV) tq = okc[qq] ? w.vd_()[lane + 64 * qq] + mu * fast_rcp(xq[qq]) : 0.0;
+                if (TCV) tq = okc[qq] ? w.vd_()[lane + 64 * qq] + (COR ? cor[qq] : mu) * fast_rcp(xq[qq]) : 0.0;
                 else tq = w.stage_()[lane + 64 * qq];       // t, parked there by the caller
                 wv[qq] = w2[qq];
                 dx[qq] = (tq - w2[qq]) * d[qq];
@@ -1094,7 +1095,11 @@ __device__ __forceinline__ void load_lp_values(WReg<MB, NQ, DA, PA>& w, const do
 // ------------------------------------------------------------------------------------------------------------------
 // solve kernel: sparse_standard_primal_normal (primal_normal.cl:287-375), one LP per wavefront
 // ------------------------------------------------------------------------------------------------------------------
-template <int MB, int NQ, bool DA, bool PA>
+// PC (PYCLLP_FLAG_PREDCORR): Mehrotra's predictor-corrector, oracle ipm_one_pc -- after the iteration's one factorisation a
+// predictor solve with mu = 0, the centering parameter from how far it gets, then the corrector solve (newton_solve with the
+// per-column target cor = mu - dx_a dz_a): one more block substitution, A'u and A v per iteration, about half the iterations
+// on config 5's structure (52.7 -> 25.5)
+template <int MB, int NQ, bool DA, bool PA, bool PC = false>
 __global__ void __launch_bounds__(256, 1)
 ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* __restrict__ bg, const double* __restrict__ cg,
                 double* __restrict__ xg, double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj,
@@ -1245,7 +1250,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* 
             s2 = wsum(s2); gam = wsum(gam); po = wsum(pp); du = wsum(dd);
             const double norms = uni(sqrt(s2));
             const double normr = uni(sqrt(wsum(r2s)));
-            const double mu = uni(o.delta * gam / nm);
+            double mu = PC ? 0.0 : uni(o.delta * gam / nm);      // PC: 0 for the predictor, set from its outcome below
             STAMP(10)
             // ---- stop tests (primal_normal.cl:256-269; oracle ipm_one_path) ----
             if (!(isfinite(normr) && isfinite(norms) && isfinite(gam))) { stat = PYCLLP_STATUS_NUMERICAL; running = false; }
@@ -1293,10 +1298,50 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* 
                 if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = -1; running = false; }
                 else {
                     double dy[MR], wv[NQ], dx[NQ], e[MR], rhn[MR];
+                    double cor[NQ];
                     bool bad;
 #pragma unroll
                     for (int r2 = 0; r2 < MR; r2++) rhn[r2] = (lane + 64 * r2 < MP) ? w.flr_()[lane + 64 * r2] : 0.0;
-                    (void)newton_solve<true>(w, okc, okr, rhn, etol, o.max_refine, mu, dy, dx, wv, e, bad STAMP_PASS);
+                    if constexpr (PC) {
+                        // ---- predictor: um holds A(d t_a) - rho with t_a = cv (mu = 0) ----
+                        w.solve();
+                        double w2[NQ], dxa[NQ], dza[NQ], tha = 0.0, ga = 0.0;
+                        w.At(w.um_(), w2);
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) {
+                            const double xq = w.stage_()[64 * NQ + lane + 64 * qq], zq = w.stage_()[128 * NQ + lane + 64 * qq];
+                            const double rx = fast_rcp(xq), rz = fast_rcp(zq);
+                            const double dq = okc[qq] ? xq * rz : 0.0;
+                            const double ta = okc[qq] ? w.vd_()[lane + 64 * qq] : 0.0;
+                            dxa[qq] = (ta - w2[qq]) * dq;
+                            dza[qq] = okc[qq] ? (-zq * dxa[qq]) * rx - zq : 0.0;
+                            if (okc[qq]) tha = fmax(tha, fmax(-dza[qq] * rz, -dxa[qq] * rx));
+                        }
+                        const double theta_a = uni(fmin(1.0 / wmax(tha), 1.0));
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) {
+                            const double xq = w.stage_()[64 * NQ + lane + 64 * qq], zq = w.stage_()[128 * NQ + lane + 64 * qq];
+                            ga += okc[qq] ? fma(theta_a, dxa[qq], xq) * fma(theta_a, dza[qq], zq) : 0.0;
+                        }
+                        const double sgm = wsum(ga) / gam;
+                        mu = uni(sgm * sgm * sgm * gam / (double)n);
+                        // ---- corrector right-hand side: A(d t_c) - rho, t_c = cv + cor / x ----
+                        wave_lds_sync();
+#pragma unroll
+                        for (int qq = 0; qq < NQ; qq++) {
+                            const double xq = w.stage_()[64 * NQ + lane + 64 * qq], zq = w.stage_()[128 * NQ + lane + 64 * qq];
+                            cor[qq] = okc[qq] ? mu - dxa[qq] * dza[qq] : 0.0;
+                            const double tq = okc[qq] ? w.vd_()[lane + 64 * qq] + cor[qq] * fast_rcp(xq) : 0.0;
+                            vx[lane + 64 * qq] = (okc[qq] ? xq * fast_rcp(zq) : 0.0) * tq;
+                        }
+                        wave_lds_sync();
+                        double Adt2[MR], dmy[MR];
+                        w.template Arow<false>(vx, Adt2, dmy);
+#pragma unroll
+                        for (int r2 = 0; r2 < MR; r2++) if (lane + 64 * r2 < MP) w.um_()[lane + 64 * r2] = okr[r2] ? Adt2[r2] - rhn[r2] : 0.0;
+                        wave_lds_sync();
+                    }
+                    (void)newton_solve<true, PC>(w, okc, okr, rhn, etol, o.max_refine, mu, dy, dx, wv, e, bad, cor STAMP_PASS);
 #pragma unroll
                     for (int qq = 0; qq < NQ; qq++) {
                         cv[qq] = w.vd_()[lane + 64 * qq];
@@ -1310,7 +1355,7 @@ ipm_wreg_kernel(WregTab T, long B, const double* __restrict__ ag, const double* 
 #pragma unroll
                         for (int qq = 0; qq < NQ; qq++) {
                             const double rx = fast_rcp(x[qq]), rz = fast_rcp(z[qq]);
-                            dz[qq] = okc[qq] ? (mu - z[qq] * dx[qq]) * rx - z[qq] : 0.0;
+                            dz[qq] = okc[qq] ? ((PC ? cor[qq] : mu) - z[qq] * dx[qq]) * rx - z[qq] : 0.0;
                             if (okc[qq]) th = fmax(th, fmax(-dz[qq] * rz, -dx[qq] * rx));
                         }
                         th = wmax(th);
@@ -1814,7 +1859,7 @@ newton_wreg_kernel(WregTab T, long B, const double* __restrict__ xg, const doubl
         double dy[MR], wv[NQ], dx[NQ];
         bool bad;
         double ed[MR];
-        const int nref = newton_solve<false>(w, okc, okr, rho, etol, o.max_refine, mu, dy, dx, wv, ed, bad STAMP_PASS);
+        const int nref = newton_solve<false>(w, okc, okr, rho, etol, o.max_refine, mu, dy, dx, wv, ed, bad, nullptr STAMP_PASS);
 #pragma unroll
         for (int r2 = 0; r2 < MR; r2++) if (okr[r2]) dyg[lp * m + lane + 64 * r2] = dy[r2];
         if (nrefg && lane == 0) nrefg[lp] = nref;
@@ -1929,13 +1974,13 @@ size_t put(std::vector<char>& host, const std::vector<T>& v) {
     return off;
 }
 
-template <int MB, int NQ, bool DA, bool PA>
+template <int MB, int NQ, bool DA, bool PA, bool PC = false>
 hipError_t do_solve(const WregTab& T, long B, const double* a, const double* b, const double* c, double* x, double* y, double* z,
                     double* pobj, double* dobj, int* status, int* iters, int* qhead, int* defer, DevOpts o, int grid,
                     hipStream_t st) {
-    hipError_t e = set_dyn_lds((const void*)ipm_wreg_kernel<MB, NQ, DA, PA>, T.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)ipm_wreg_kernel<MB, NQ, DA, PA, PC>, T.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA, PA>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, a, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL((ipm_wreg_kernel<MB, NQ, DA, PA, PC>), dim3(grid), dim3(64 * T.wpb), T.lds_bytes, st, T, B, a, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, defer, o);
     return hipGetLastError();
 }
@@ -1961,6 +2006,8 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, false, do_solve<MB, NQ, DA, false>, do_solve_hsd<MB, NQ, DA, false>, do_newton<MB, NQ, DA> }
 #define WVARIANT_PA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true>, do_solve_hsd<MB, NQ, false, true>, nullptr }
+// predictor-corrector kernels of the table variants (fourth translation unit): only `solve` is meaningful
+#define WVARIANT_PC(MB, NQ) { MB, NQ, false, false, do_solve<MB, NQ, false, false, true>, nullptr, nullptr }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
 const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
@@ -2000,6 +2047,16 @@ namespace { [[maybe_unused]] const WVariant kWVariantsPA_instantiate[] = WVARIAN
 #else
 extern const WVariant kWVariantsPA[] = WVARIANTS_PA;
 extern const int kNumWVariantsPA = sizeof(kWVariantsPA) / sizeof(kWVariantsPA[0]);
+#endif
+#endif
+#if WREG_PART == 3
+#define WVARIANTS_PC { WVARIANT_PC(1, 4), WVARIANT_PC(2, 4), WVARIANT_PC(3, 4), WVARIANT_PC(4, 2), WVARIANT_PC(4, 4), WVARIANT_PC(5, 6), \
+                       WVARIANT_PC(6, 6), WVARIANT_PC(7, 6), WVARIANT_PC(8, 4), WVARIANT_PC(8, 6), WVARIANT_PC(8, 8) }
+#ifdef __HIP_DEVICE_COMPILE__
+namespace { [[maybe_unused]] const WVariant kWVariantsPC_instantiate[] = WVARIANTS_PC; }
+#else
+extern const WVariant kWVariantsPC[] = WVARIANTS_PC;
+extern const int kNumWVariantsPC = sizeof(kWVariantsPC) / sizeof(kWVariantsPC[0]);
 #endif
 #endif
 #if WREG_PART == 0
@@ -2255,6 +2312,7 @@ void wreg_plan_free(WregPlan* p) {
 int wreg_lds_bytes(const WregPlan* p) { return p ? p->tab.lds_bytes : 0; }
 int wreg_block_threads(const WregPlan* p) { return p ? 64 * p->tab.wpb : 0; }
 int wreg_variant(const WregPlan* p) { return p ? (p->da ? 2 : 1) : 0; }
+int wreg_has_predcorr(const WregPlan* p) { return (p && !p->da && !p->pa) ? 1 : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)
@@ -2276,7 +2334,15 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* a_batch, const d
     long grid = std::min(cus, (B + p->tab.wpb - 1) / p->tab.wpb);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
-    return ((o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve)(p->tab, B, a_batch, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
+    wsolve_fn fn = (o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve;
+    if ((o.flags & PYCLLP_FLAG_PREDCORR) && !(o.flags & PYCLLP_FLAG_HSD)) {
+        fn = nullptr;
+        if (!p->da && !p->pa)
+            for (int i = 0; i < kNumWVariantsPC; i++)
+                if (kWVariantsPC[i].mb == p->mb && kWVariantsPC[i].nq == p->nq) fn = kWVariantsPC[i].solve;
+        if (!fn) return hipErrorNotSupported;
+    }
+    return fn(p->tab, B, a_batch, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);
 }
 
 hipError_t wreg_launch_newton(WregPlan* p, long B, const double* x, const double* z, const double* y, const double* b,

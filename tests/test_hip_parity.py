@@ -607,6 +607,38 @@ def test_predictor_corrector_options_and_large_lps():
     assert s.iters.mean() < 0.8 * oracle_on(lp)["iters"].mean()
 
 
+def test_predictor_corrector_on_the_sparse_path():
+    """The same option on the wavefront-per-LP kernel: config 5's golden LPs (reference hsd.c) to 1e-8, the oracle's
+    ipm_one_pc LP by LP, about half the iterations of the reference's rule on this structure (52.7 -> 25.5); a smaller
+    sparse shape; and where the option is not implemented (per-problem A, dense-image variant) it is refused, not ignored."""
+    g = golden("config_sparse_128x256.npz")
+    import scipy.sparse as sp
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(128, 256))
+    lp = StandardLP(SparseMatrix(matrix=A), g["b"], g["c"], 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](predcorr=True, hsd=False)
+    lp.init(s)
+    st = lp.solve(s)
+    assert s.launch_info()["kernel"] == "wave" and (st == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    r = oracle_on(lp, flags=128)
+    assert np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    assert s.iters.mean() < 0.6 * oracle_on(lp)["iters"].mean()
+    A2, b2, c2 = problems.random_sparse_arrays(40, 90, 64, density=0.1, seed=5)
+    lp2 = StandardLP(SparseMatrix(matrix=A2), b2, c2, 0.0).to_equality_form()
+    s2 = solver_registry["hip_sparse_primal_normal"](predcorr=True)          # default hsd='auto'
+    lp2.init(s2)
+    assert (lp2.solve(s2) == 0).all()
+    r2 = oracle_on(lp2, flags=128)
+    assert np.abs(s2.iters.astype(int) - r2["iters"]).max() <= 1 and rel_err(s2.primal_obj, r2["pobj"]).max() < 1e-9
+    Ad, bd, cd = problems.random_dense_arrays(64, 64, 8, seed=1)              # dense-image variant of the wave kernel
+    lpd = StandardLP(SparseMatrix(matrix=Ad), bd, cd, 0.0).to_equality_form()
+    sd = solver_registry["hip_dense_primal_normal"](predcorr=True, hsd=False)
+    lpd.init(sd)
+    with pytest.raises(NotImplementedError):
+        lpd.solve(sd)
+
+
 # ---- homogeneous self-dual embedding (PYCLLP_FLAG_HSD, SURVEY 8f-3) -----------------------------------------------------
 
 def test_hsd_statuses_against_reference_highs_and_oracle():
