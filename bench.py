@@ -134,13 +134,15 @@ class Workload(object):
     """One synthetic batch resident on the device + the solver that runs it.  Everything the JSON record of a workload
     needs is derived here, so that the headline and the secondary records are built by the same code."""
 
-    def __init__(self, name, B, rank, dev, reserve=0, hsd=False, predcorr=False):
+    def __init__(self, name, B, rank, dev, reserve=0, hsd=False, predcorr=False, r=None):
         import torch
         from pycllp_amd import problems
         from pycllp_amd.lp import SparseMatrix, EqualityLP, StandardLP
         from pycllp_amd.solvers import solver_registry
         self.name, self.B, self.hsd, self.dev = name, B, bool(hsd), dev
         self.predcorr = bool(predcorr)      # PYCLLP_FLAG_PREDCORR: Mehrotra's predictor-corrector (an option, never the headline)
+        self.r = r                          # step fraction other than the reference's R = 0.9 (primal_normal.cl:11); option records only
+        extra = {} if r is None else {"r": float(r)}
         self.per_a = name == "perA"
         self.sparse = name in ("sparse5", "perA")
         self.a_values = None
@@ -160,19 +162,21 @@ class Workload(object):
                 lp = StandardLP(SparseMatrix(matrix=A), b[:1], c[:1], 0.0).to_equality_form()
             # hsd=False: the reference's algorithm (primal_normal.cl path following), what the plugin's default hsd='auto'
             # runs first; hsd=True: the homogeneous self-dual variant (41 instead of 52 iterations, two solves per iteration)
-            solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve)
+            solver = solver_registry["hip_sparse_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve, **extra)
             self.what = ("%d random LPs per GPU, shared SPARSE A (m=%d, n=%d, density 0.025, rows>=3 and columns>=1 non-zeros) "
                          "-> equality form N=%d, b,c~U[0.5,1.5), seed 0 (BASELINE.json configs[4] per-GPU share)%s"
                          % (B, m_, n_, n_ + m_, "; PER-PROBLEM VALUES of A on that structure (SURVEY 8f-4; shared x U[0.75,1.25))"
                             if self.per_a else ""))
             if self.predcorr:
                 self.what += "; OPTION predcorr=True (Mehrotra predictor-corrector: one factorisation, two solves per iteration)"
+            if r is not None:
+                self.what += "; OPTION step fraction r = %g (reference: 0.9)" % r
         else:
             m_, n_ = {"dense3": (M, N_STD), "dense2": (16, 32), "dense100": (100, 80)}[name]
             A, b, c = problems.random_dense_arrays(m_, n_, B, seed=0, shard=rank)
             Ae, be, ce = problems.equality_arrays(A, b, c)
             lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
-            solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve)
+            solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve, **extra)
             cfg = {"dense3": "BASELINE.json configs[2]", "dense2": "BASELINE.json configs[1]",
                    "dense100": "a dense LP beyond the lane-group kernels; m = 100 is the reference's own kernel-test size, "
                                "tests/test_ldl.py:226-238"}[name]
@@ -180,6 +184,8 @@ class Workload(object):
                          "b,c~U[0.5,1.5), seed 0 (%s)" % (B, m_, n_, n_ + m_, cfg))
             if self.predcorr:
                 self.what += "; OPTION predcorr=True (Mehrotra predictor-corrector: one factorisation, two solves per iteration)"
+            if r is not None:
+                self.what += "; OPTION step fraction r = %g (reference: 0.9)" % r
         self.m, self.n, self.N = m_, n_, n_ + m_
         self.A, self.b_std, self.c_std = A, b, c
         self.lp, self.solver = lp, solver
@@ -304,12 +310,12 @@ class Workload(object):
                              chunk=256 if self.m <= 32 else 16)
 
 
-def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None, predcorr=False):
+def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None, predcorr=False, r=None):
     """One secondary record: the workload resident in HBM, `warmup` untimed and `steps` timed passes (HIP events around
     every launch on the launch stream, wall clock between two device synchronisations), parity, roofline, CPU reference."""
     import torch
     t_build = time.perf_counter()
-    w = Workload(name, B, 0, dev, hsd=hsd, predcorr=predcorr)
+    w = Workload(name, B, 0, dev, hsd=hsd, predcorr=predcorr, r=r)
     for k in range(warmup):
         w.step(k % 2)
     torch.cuda.synchronize(dev)
@@ -325,7 +331,8 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
     info = w.launch_info()
     status = buf["status"].cpu().numpy(); iters = buf["iters"].cpu().numpy()
     pobj = buf["pobj"].cpu().numpy(); dobj = buf["dobj"].cpu().numpy()
-    rec = {"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if predcorr else ""), "value": B * steps / elapsed, "unit": "LPs/s", "steps": steps,
+    rec = {"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if predcorr else "") + ("_r%g" % r if r is not None else ""),
+           "value": B * steps / elapsed, "unit": "LPs/s", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "kernel_ms": kern_ms,
            "config": {"workload": w.what, "lps_per_gpu": B, "m": w.m, "n": w.n, "N_equality": w.N, "kernel": w.kernel_name(info)},
            "solved_optimal": int((status == 0).sum()), "mean_ipm_iterations": float(iters.mean()),
@@ -336,10 +343,11 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
     return rec
 
 
-# (workload, LPs, hsd, predcorr)
-SECONDARY = (("dense2", 4096, False, False), ("sparse5", 16384, False, False), ("sparse5", 16384, True, False),
-             ("perA", 16384, False, False), ("dense100", 16384, False, False),
-             ("dense3", 65536, False, True), ("sparse5", 16384, False, True))
+# (workload, LPs, hsd, predcorr, step fraction or None = the reference's 0.9)
+SECONDARY = (("dense2", 4096, False, False, None), ("sparse5", 16384, False, False, None), ("sparse5", 16384, True, False, None),
+             ("perA", 16384, False, False, None), ("dense100", 16384, False, False, None),
+             ("dense3", 65536, False, True, None), ("dense3", 65536, False, True, 0.99),
+             ("sparse5", 16384, False, True, None), ("sparse5", 16384, False, True, 0.99))
 
 
 def main():
@@ -509,17 +517,17 @@ def main():
             # the other single-GPU configurations under the same clock (records; `value` above stays the headline's)
             del wl
             sec, cpu5 = [], None
-            for name, Bs, hsd, pc in SECONDARY:
+            for name, Bs, hsd, pc, rr in SECONDARY:
                 try:
                     # same LPs, same reference solver: timed once (the headline's own CPU leg serves dense3_predcorr)
                     reuse = cpu5 if (name == "sparse5" and (hsd or pc)) else (cpu if name == "dense3" else None)
-                    r = measure_secondary(name, Bs, dev, steps=5, warmup=2, hsd=hsd, predcorr=pc,
+                    r = measure_secondary(name, Bs, dev, steps=5, warmup=2, hsd=hsd, predcorr=pc, r=rr,
                                           cpu_seconds=None if args.no_cpu_baseline else 4.0, cpu_from=reuse)
                     if name == "sparse5" and not hsd and not pc:
                         cpu5 = r["cpu_baseline"]
                     sec.append(r)
                 except Exception as exc:      # a secondary record must never cost the headline its line
-                    sec.append({"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if pc else ""),
+                    sec.append({"workload": name + ("_hsd" if hsd else "") + ("_predcorr" if pc else "") + ("_r%g" % rr if rr else ""),
                                 "error": "%s: %s" % (type(exc).__name__, exc)})
             out["secondary"] = sec
         sys.stdout.flush()

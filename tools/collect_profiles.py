@@ -16,13 +16,16 @@ def rd(f):
     return d
 
 traffic = {}
-for wl, lps, kern in (("dense3", 65536, "ipm_group_kernel<32,96,slack-aware>"), ("sparse5", 16384, "ipm_wreg_kernel<8,6>")):
+for wl, lps, kern in (("dense3", 65536, "ipm_group_kernel<32,96,slack-aware>"), ("sparse5", 16384, "ipm_wreg_kernel<8,6>"),
+                      ("perA", 16384, "ipm_wreg_kernel<8,6,per-problem A>")):
+    if not glob.glob(G + "/stats_%s/*/*kernel_stats.csv" % wl):
+        continue
     shutil.copy(glob.glob(G + "/stats_%s/*/*kernel_stats.csv" % wl)[0], P + "/kernel_stats_%s.csv" % wl)
     rows = list(csv.DictReader(open(glob.glob(G + "/stats_%s/*/*kernel_trace.csv" % wl)[0])))
     ds = []
     with open(P + "/kernel_trace_durations_%s.txt" % wl, "w") as fo:
         fo.write("# per-launch durations (ms) of the solve kernels, in launch order, from rocprofv3 --kernel-trace of\n# `python3 bench.py %s--no-cpu-baseline` "
-                 "(3 warm-up + 10 timed full-size launches, then the parity solve)\n" % ("--workload sparse5 " if wl == "sparse5" else ""))
+                 "(3 warm-up + 10 timed full-size launches, then the parity solve)\n" % ("--workload %s " % wl if wl != "dense3" else ""))
         for r in rows:
             n = r["Kernel_Name"]
             if "ipm_" in n or "hsd_" in n:
@@ -54,6 +57,6 @@ for wl, lps, kern in (("dense3", 65536, "ipm_group_kernel<32,96,slack-aware>"), 
     traffic[wl] = {"lps_per_launch": lps, "bytes_per_launch": f + w, "fetch_bytes_corrected_x2": f, "write_bytes": w, "kernel": kern,
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh, via tools/prof_round.sh); KB units; FETCH_SIZE "
                              "doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM; means over the full-size launches of the pass",
-                   "source": "rocprofv3 PMC passes of round 2 at commit %s (profiles/%s/pmc_summary_%s.txt); not re-measured in the bench run itself" % (commit, name, wl)}
+                   "source": "rocprofv3 PMC passes at commit %s (profiles/%s/pmc_summary_%s.txt); not re-measured in the bench run itself" % (commit, name, wl)}
     print(wl, "steady %.3f ms" % steady, "traffic %.0f B/LP" % ((f + w) / lps))
 json.dump(traffic, open(os.path.join(R, "profiles", "hbm_traffic.json"), "w"), indent=1)
