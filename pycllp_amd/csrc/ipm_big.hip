@@ -37,6 +37,8 @@ struct BigTab {
     const double* csr_val; const int* csr_ptr; const int* csr_col;   // A by rows
     const double* csc_val; const int* csc_ptr; const int* csc_row;   // A by columns
     const double* img;                   // [ks][imgR][4]
+    const double* img_rm;                // dense mode: the dense columns row-major [m][nd] (A'u: thread = column, coalesced)
+    const double* img_cm;                // ... and column-major [nd][imgR] (A v: thread = row, coalesced)
     int n_ent;                           // term-list mode: entries (i, k), i >= k, of M with their terms a_ij a_kj, column j
     const int* ent_dst; const int* ent_dst2; const int* ent_ptr; const double* term_w; const int* term_col;
 };
@@ -107,8 +109,29 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
     const double eta = 1.0 - o.delta, einf = 100.0 * o.eps;
     const double nm = (double)(n + m);
 
-    // A'u for this thread's columns, u in LDS
+    // A'u for this thread's columns, u in LDS.  Dense A: straight from the row-major image -- the threads of a wave read
+    // consecutive columns of one row (one coalesced L2 read per row, u_i a broadcast), four rows in flight per trip; the identity
+    // columns behind the dense ones pick their own u_i.  Sparse A: the CSC arrays.
     auto At_cols = [&](const double* u, double (&out)[BNC]) {
+        if (T.dense) {
+            const int nd = T.nd;
+#pragma unroll
+            for (int k = 0; k < BNC; k++) {
+                const int j = tid + BT * k;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                if (j < nd) {
+                    const double* col = T.img_rm + j;
+                    int i = 0;
+                    for (; i + 4 <= m; i += 4) {
+                        const double v0 = col[(size_t)i * nd], v1 = col[(size_t)(i + 1) * nd], v2 = col[(size_t)(i + 2) * nd], v3 = col[(size_t)(i + 3) * nd];
+                        a0 = fma(v0, u[i], a0); a1 = fma(v1, u[i + 1], a1); a2 = fma(v2, u[i + 2], a2); a3 = fma(v3, u[i + 3], a3);
+                    }
+                    for (; i < m; i++) a0 = fma(col[(size_t)i * nd], u[i], a0);
+                }
+                out[k] = (j < nd) ? (a0 + a1) + (a2 + a3) : ((j < n) ? u[j - nd] : 0.0);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < BNC; k++) {
             const int j = tid + BT * k;
@@ -117,12 +140,34 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             out[k] = acc;
         }
     };
-    // (A v)_i for row i = tid (< m), v in LDS
-    auto A_row = [&](const double* v) {
-        double acc = 0.0;
-        if (tid < m) for (int p = csr_ptr[tid]; p < csr_ptr[tid + 1]; p++) acc = fma(csr_val[p], v[csr_col[p]], acc);
-        return acc;
+    // (A v)_i for row i = tid (< m), v in LDS; with dg also diag(A diag(d) A')_i (d in vd) from the same pass.  Dense A: the
+    // column-major image (consecutive rows = consecutive threads: coalesced), v_j a broadcast, + the row's identity column.
+    auto A_row_dg = [&](const double* v, bool dg, double& mdg) {
+        double a0 = 0.0, a1 = 0.0, m0 = 0.0, m1 = 0.0;
+        if (T.dense) {
+            if (tid < m) {
+                const int nd = T.nd, R = T.imgR;
+                const double* row = T.img_cm + tid;
+                int j = 0;
+                for (; j + 2 <= nd; j += 2) {
+                    const double v0 = row[(size_t)j * R], v1 = row[(size_t)(j + 1) * R];
+                    a0 = fma(v0, v[j], a0); a1 = fma(v1, v[j + 1], a1);
+                    if (dg) { m0 = fma(v0 * v0, vd[j], m0); m1 = fma(v1 * v1, vd[j + 1], m1); }
+                }
+                for (; j < nd; j++) { const double v0 = row[(size_t)j * R]; a0 = fma(v0, v[j], a0); if (dg) m0 = fma(v0 * v0, vd[j], m0); }
+                if (T.n_sl) { a0 += v[nd + tid]; if (dg) m0 += vd[nd + tid]; }
+            }
+        } else if (tid < m) {
+            for (int p = csr_ptr[tid]; p < csr_ptr[tid + 1]; p++) {
+                const double a = csr_val[p]; const int j = csr_col[p];
+                a0 = fma(a, v[j], a0);
+                if (dg) m0 = fma(a * a, vd[j], m0);
+            }
+        }
+        mdg = m0 + m1;
+        return a0 + a1;
     };
+    auto A_row = [&](const double* v) { double dm; return A_row_dg(v, false, dm); };
 
     // ---- M = A diag(d) A' (d in vd) into the blocks ----
     auto gram = [&]() {
@@ -422,12 +467,8 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             }
             __syncthreads();
             // ---- right-hand side A(d t) - rho (embedding: A(d r1) - eta rho) and diag(M) from one pass over the row ----
-            double adt = 0.0, mdg = 0.0;
-            if (tid < m)
-                for (int p = csr_ptr[tid]; p < csr_ptr[tid + 1]; p++) {
-                    const double a = csr_val[p]; const int j = csr_col[p];
-                    adt = fma(a, vx[j], adt); mdg = fma(a * a, vd[j], mdg);
-                }
+            double mdg = 0.0;
+            const double adt = A_row_dg(vx, true, mdg);
             const double beta2 = bmax((tid < m) ? fabs(mdg) : 0.0, red, tid);     // ldl.cl:280-294
             if (hsd) {
                 // M p = A(d c) - b first; q's right-hand side waits in qv
@@ -625,15 +666,21 @@ int big_plan_create(int m, int n, int nnz, const double* val, const int* ptr, co
     double n_terms = 0.0;
     for (int j = 0; j < n; j++) { const double l = cptr[j + 1] - cptr[j]; n_terms += l * (l + 1) / 2; }
     T.dense = n_terms > 0.125 * (double)MP * MP * nd ? 1 : 0;
-    std::vector<double> img;
+    std::vector<double> img, img_rm, img_cm;
     std::vector<int> ent_dst, ent_dst2, ent_ptr, term_col;
     std::vector<double> term_w;
     if (T.dense) {
         T.nd = nd; T.n_sl = n - nd; T.ks = (nd + 3) / 4; T.imgR = MP;
         img.assign((size_t)T.ks * MP * 4, 0.0);
+        img_rm.assign((size_t)m * nd, 0.0);
+        img_cm.assign((size_t)nd * MP, 0.0);
         for (int i = 0; i < m; i++)
             for (int e = ptr[i]; e < ptr[i + 1]; e++)
-                if (col[e] < nd) img[((size_t)(col[e] >> 2) * MP + i) * 4 + (col[e] & 3)] = val[e];
+                if (col[e] < nd) {
+                    img[((size_t)(col[e] >> 2) * MP + i) * 4 + (col[e] & 3)] = val[e];
+                    img_rm[(size_t)i * nd + col[e]] = val[e];
+                    img_cm[(size_t)col[e] * MP + i] = val[e];
+                }
     } else {
         struct Term { int key, colj; double w; };
         std::vector<Term> terms;
@@ -671,7 +718,8 @@ int big_plan_create(int m, int n, int nnz, const double* val, const int* ptr, co
     std::vector<int> csr_ptr(ptr, ptr + m + 1), csr_col(col, col + nnz);
     const size_t a1 = put(host, csr_val), a2 = put(host, csr_ptr), a3 = put(host, csr_col), a4 = put(host, cval),
                  a5 = put(host, cptr), a6 = put(host, crow), a7 = put(host, img), a8 = put(host, ent_dst),
-                 a9 = put(host, ent_dst2), a10 = put(host, ent_ptr), a11 = put(host, term_w), a12 = put(host, term_col);
+                 a9 = put(host, ent_dst2), a10 = put(host, ent_ptr), a11 = put(host, term_w), a12 = put(host, term_col),
+                 a13 = put(host, img_rm), a14 = put(host, img_cm);
     hipError_t e = hipMalloc(&P->dev_blob, host.size());
     if (e == hipSuccess) e = hipMemcpyAsync(P->dev_blob, host.data(), host.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -679,7 +727,7 @@ int big_plan_create(int m, int n, int nnz, const double* val, const int* ptr, co
     char* db = (char*)P->dev_blob;
     T.csr_val = (const double*)(db + a1); T.csr_ptr = (const int*)(db + a2); T.csr_col = (const int*)(db + a3);
     T.csc_val = (const double*)(db + a4); T.csc_ptr = (const int*)(db + a5); T.csc_row = (const int*)(db + a6);
-    T.img = (const double*)(db + a7);
+    T.img = (const double*)(db + a7); T.img_rm = (const double*)(db + a13); T.img_cm = (const double*)(db + a14);
     T.ent_dst = (const int*)(db + a8); T.ent_dst2 = (const int*)(db + a9); T.ent_ptr = (const int*)(db + a10);
     T.term_w = (const double*)(db + a11); T.term_col = (const int*)(db + a12);
     *out = P;
