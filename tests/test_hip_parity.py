@@ -537,9 +537,18 @@ def test_repeat_solve_warm_start_through_the_plugin_api(name, m, n):
     r = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8, x0=x0, y0=y0, z0=z0, flags=1)
     full = port.dense_solve(lp.A.todense(), lp.b, lp.c, nthreads=8)
     assert (s.status == 0).all()
-    # a warm start sits on the boundary (x z ~ 1e-10): the first steps are rounding sensitive, so kernel and oracle may be a
-    # few iterations apart on a few LPs -- identical on most, and well below the cold count in the median
-    diff = np.abs(s.iters.astype(int) - r["iters"])
+    # What is comparable (round 3, tests/dev/warm_band.py + warm_outlier.py, profiles/r03/warm_start_band.txt): a warm start sits
+    # on the boundary (x z ~ 1e-10), where rounding-level differences between kernel and oracle grow ~30x per iteration
+    # (2e-15 after one iteration, 1e-13 after three, 4e-10 after eight), so the two may stop a few iterations apart:
+    # measured over 3 x 300 LPs and two kernel builds (rho carried / recomputed) 96-98 % within 1, at most 6.  NOT comparable
+    # is the exit iteration of a warm start that JAMS: for about one LP in 300 the old optimum is 2e-3 infeasible for the
+    # new data, the steps collapse (x, z -> 1e-39, |rho| stalls at 1e-5) and the reference's 10x-growth heuristic ends the run
+    # at an iteration set by rounding noise (oracle: 55, status 2); the plugin's default hsd='auto' then re-solves that LP
+    # cold on the embedding (19 iterations, optimal).  So: iteration counts are compared where the oracle's warm start ends
+    # optimal; for every LP the verdict and the optimum are.
+    okw = r["status"] == 0
+    assert okw.mean() > 0.98
+    diff = np.abs(s.iters.astype(int) - r["iters"])[okw]
     assert (diff <= 1).mean() > 0.9 and diff.max() <= 8
     assert np.median(s.iters) < 0.7 * np.median(it_cold)
     assert rel_err(s.primal_obj, full["pobj"]).max() < 1e-8
