@@ -28,6 +28,9 @@
 
 namespace {
 
+#ifndef BIG_PAIRS_PER_TRIP
+#define BIG_PAIRS_PER_TRIP 2             // block pairs of the trailing update whose reads are in flight together (per wave)
+#endif
 constexpr int BT = 256;                  // threads per workgroup
 constexpr int BNC = BIG_MAX_N / BT;      // N-vector registers per thread
 
@@ -68,7 +71,8 @@ __host__ __device__ inline size_t big_lds_doubles(int MB, int n, bool m_in_lds) 
     return (m_in_lds ? (size_t)MB * (MB + 1) / 2 * 256 : 0) + (size_t)MB * 256 + 2 * NPv + 9 * MP + 272 + 256 + 32;
 }
 
-__global__ void __launch_bounds__(BT, 1)
+template <int WGPC>       // workgroups per CU the instance is compiled for (2: 256 registers per lane; 3: 168, more spills, more overlap)
+__global__ void __launch_bounds__(BT, WGPC)
 ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg, double* __restrict__ xg,
                double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj, double* __restrict__ dobj,
                int* __restrict__ status, int* __restrict__ iters, int* __restrict__ queue, double* ws, double nwt_mu,
@@ -282,22 +286,47 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                 for (int r = 0; r < 4; r++) { ymax = fmax(ymax, acc[r] * acc[r] * rDr[r]); blk[r * 64 + lane] = acc[r]; }
             }
             __syncthreads();
-            // ---- trailing update: M_JI -= Y_KJ' D_K^-1 Y_KI, K < J <= I (the diagonal blocks included, in full) ----
-            int cnt = 0;
-            for (int J = K + 1; J < MB; J++) {
-                const double* yj = Mw + (size_t)bidx(K, J) * 256;
-                for (int I = J; I < MB; I++, cnt++) {
-                    if ((cnt & 3) != wave) continue;
-                    const double* yi = Mw + (size_t)bidx(K, I) * 256;
-                    double* mji = Mw + (size_t)bidx(J, I) * 256;
-                    double4_t acc;
-                    double yn[4], yb[4];
+            // ---- trailing update: M_JI -= Y_KJ' D_K^-1 Y_KI, K < J <= I (the diagonal blocks included, in full).  The pairs
+            //      (J, I) in row-major order are dealt round-robin to the waves; a wave takes BIG_PAIRS_PER_TRIP of its pairs per trip -- all
+            //      their block reads in flight before the first MFMA -- because one round trip to a block that lives in the L2
+            //      workspace costs more than the 16 MFMAs it feeds ----
+            {
+                const int nt = MB - K - 1;                        // trailing block rows
+                const int npair = nt * (nt + 1) / 2;
+                constexpr int PT = BIG_PAIRS_PER_TRIP;
+                for (int p0 = wave; p0 < npair; p0 += 4 * PT) {
+                    double4_t acc[PT];
+                    double yn[PT][4], yb[PT][4];
+                    double* dst[PT];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) { acc[r] = mji[r * 64 + lane]; yn[r] = -(yj[r * 64 + lane] * rDr[r]); yb[r] = yi[r * 64 + lane]; }
+                    for (int u = 0; u < PT; u++) {
+                        const int pp = p0 + 4 * u;
+                        const bool on = pp < npair;
+                        // pair index -> (row a, column b) of the upper triangle of an nt x nt array, a <= b, row-major
+                        int a = 0, rem = on ? pp : 0;
+                        while (rem >= nt - a) { rem -= nt - a; a++; }
+                        const int J = K + 1 + a, I = J + rem;
+                        const double* yj = Mw + (size_t)bidx(K, J) * 256;
+                        const double* yi = Mw + (size_t)bidx(K, I) * 256;
+                        dst[u] = on ? Mw + (size_t)bidx(J, I) * 256 : nullptr;
 #pragma unroll
-                    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(yn[s], yb[s], acc, 0, 0, 0);
+                        for (int r = 0; r < 4; r++) {
+                            acc[u][r] = dst[u] ? dst[u][r * 64 + lane] : 0.0;
+                            yn[u][r] = -(yj[r * 64 + lane] * rDr[r]);
+                            yb[u][r] = yi[r * 64 + lane];
+                        }
+                    }
 #pragma unroll
-                    for (int r = 0; r < 4; r++) mji[r * 64 + lane] = acc[r];
+                    for (int u = 0; u < PT; u++) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(yn[u][s4], yb[u][s4], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PT; u++)
+                        if (dst[u]) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) dst[u][r * 64 + lane] = acc[u][r];
+                        }
                 }
             }
             __syncthreads();
@@ -312,10 +341,24 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
         if (wave == 0) {
             for (int I = 0; I < MB; I++) {          // forward, row oriented: t_I = W_I (s_I - sum_{K<I} Y_KI' D_K^-1 t_K)
                 double p = 0.0;
-                for (int K = 0; K < I; K++) {
-                    const double* blk = Mw + (size_t)bidx(K, I) * 256;
+                {   // (four blocks per trip: sixteen reads in flight; blocks (0..I-1, I) are contiguous)
+                    const double* col = Mw + (size_t)bidx(0, I) * 256;
+                    int K = 0;
+                    for (; K + 4 <= I; K += 4) {
+                        double bv[16];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) p = fma(blk[r * 64 + lane], tdv[16 * K + 4 * r + q], p);
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) bv[4 * u + r] = col[(size_t)(K + u) * 256 + r * 64 + lane];
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) p = fma(bv[4 * u + r], tdv[16 * (K + u) + 4 * r + q], p);
+                    }
+                    for (; K < I; K++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) p = fma(col[(size_t)K * 256 + r * 64 + lane], tdv[16 * K + 4 * r + q], p);
+                    }
                 }
                 double rC = um[16 * I + c16];
                 if (I > 0) rC -= quad_sum(p);
@@ -331,11 +374,28 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             }
             for (int K = MB - 1; K >= 0; K--) {     // backward: x_K = W_K' D_K^-1 (t_K - sum_{I>K} Y_KI x_I)
                 double pr[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int I = K + 1; I < MB; I++) {
-                    const double* blk = Mw + (size_t)bidx(K, I) * 256;
-                    const double xC = um[16 * I + c16];
+                {
+                    int I = K + 1;
+                    for (; I + 4 <= MB; I += 4) {
+                        double bv[16], xC[4];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) pr[r] = fma(blk[r * 64 + lane], xC, pr[r]);
+                        for (int u = 0; u < 4; u++) {
+                            const double* blk = Mw + (size_t)bidx(K, I + u) * 256;
+                            xC[u] = um[16 * (I + u) + c16];
+#pragma unroll
+                            for (int r = 0; r < 4; r++) bv[4 * u + r] = blk[r * 64 + lane];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) pr[r] = fma(bv[4 * u + r], xC[u], pr[r]);
+                    }
+                    for (; I < MB; I++) {
+                        const double* blk = Mw + (size_t)bidx(K, I) * 256;
+                        const double xC = um[16 * I + c16];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) pr[r] = fma(blk[r * 64 + lane], xC, pr[r]);
+                    }
                 }
                 double px = 0.0;
 #pragma unroll
@@ -706,8 +766,10 @@ int big_plan_create(int m, int n, int nnz, const double* val, const int* ptr, co
         ent_ptr.push_back((int)terms.size());
         T.n_ent = (int)ent_dst.size();
     }
-    // ---- LDS plan: the blocks in LDS when they fit ----
-    T.m_in_lds = big_lds_doubles(MB, n, true) * sizeof(double) <= (size_t)max_lds ? 1 : 0;
+    // ---- LDS plan: the blocks in LDS only when two workgroups still fit a CU with them -- measured (round 3,
+    //      profiles/r03/large_lp_kernel.txt): a second resident workgroup is worth more than LDS-resident blocks (m = 144 with
+    //      the blocks in LDS and one workgroup per CU: 22 k LPs/s; with the blocks in the L2 workspace and two: 35 k, three: 44 k) ----
+    T.m_in_lds = big_lds_doubles(MB, n, true) * sizeof(double) * 2 <= (size_t)max_lds ? 1 : 0;
     const size_t lds = big_lds_doubles(MB, n, T.m_in_lds != 0) * sizeof(double);
     if (lds > (size_t)max_lds) { delete P; return 1; }
     T.lds_bytes = (int)lds;
@@ -747,17 +809,24 @@ static hipError_t big_launch(BigPlan* p, long B, const double* b, const double* 
                              double* dobj, int* status, int* iters, int* qhead, double mu, double* nwt_dy, int* nwt_nref,
                              DevOpts o, int num_cu, hipStream_t st, int* grid_out) {
     long cus = (long)num_cu - o.reserve_cus > 0 ? (long)num_cu - o.reserve_cus : 1;
+    // two workgroups per CU where the LDS allows it (256 registers per lane each): the kernel is bound by the latency of its
+    // L2 / LDS round trips, and a second workgroup fills them
+    // workgroups per CU: the kernel is bound by the latency of its L2 / LDS round trips, co-resident workgroups fill them.
+    // Three where the LDS allows (the instance compiled for 168 registers per lane), else two, else one.
+    const long per_cu = (3 * (long)p->tab.lds_bytes <= 160 * 1024) ? 3 : ((2 * (long)p->tab.lds_bytes <= 160 * 1024) ? 2 : 1);
+    cus *= per_cu;
+    auto kern = (per_cu == 3) ? ipm_big_kernel<3> : ipm_big_kernel<2>;
     long grid = std::min(cus, B);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
-    hipError_t e = set_dyn_lds((const void*)ipm_big_kernel, p->tab.lds_bytes);
+    hipError_t e = set_dyn_lds((const void*)kern, p->tab.lds_bytes);
     if (e != hipSuccess) return e;
     double* ws = nullptr;
     if (p->ws_doubles_per_block) {
         e = hipMallocAsync((void**)&ws, sizeof(double) * p->ws_doubles_per_block * (size_t)grid, st);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(ipm_big_kernel, dim3((unsigned)grid), dim3(BT), p->tab.lds_bytes, st, p->tab, B, b, c, x, y, z, pobj, dobj,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BT), p->tab.lds_bytes, st, p->tab, B, b, c, x, y, z, pobj, dobj,
                        status, iters, qhead, ws, mu, nwt_dy, nwt_nref, o);
     e = hipGetLastError();
     if (ws) { hipError_t e2 = hipFreeAsync(ws, st); if (e == hipSuccess) e = e2; }

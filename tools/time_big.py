@@ -42,12 +42,12 @@ for kind, m, n, B, dens in CASES:
     st = r["status"].cpu().numpy(); it = r["iters"].cpu().numpy()
     info = s.launch_info()
     cpu = ""
-    if hsd_ref.available():
+    if hsd_ref.available() and not os.environ.get("PYCLLP_HIP_LIB"):
         k = 4
         t = time.perf_counter(); rr = hsd_ref.solve_standard(A, b[:k], c[:k]); dc = (time.perf_counter() - t) / k
         err = np.abs(r["pobj"][:k].cpu().numpy() - rr["pobj"]) / np.maximum(1.0, np.abs(rr["pobj"]))
         cpu = "  reference hsd.c %.1f ms/LP on one core (%.0f LPs/s), objectives within %.1e of it" % (1e3 * dc, 1.0 / dc, err.max())
-    print("%-6s m=%3d n=%4d %s B=%5d: %8.1f ms = %9.0f LPs/s  (%s, %d B LDS, all optimal: %s, mean iters %.1f)%s"
+    print("%-6s m=%3d n=%4d %s B=%5d: %8.1f ms = %9.0f LPs/s  (%s, %d B LDS, status counts %s, mean iters %.1f)%s"
           % (kind, m, n, ("density %.2f" % dens) if dens else "", B, 1e3 * dt, B / dt, info["variant"], info["lds_bytes"],
-             bool((st == 0).all()), it.mean(), cpu))
+             dict(zip(*[a.tolist() for a in np.unique(st, return_counts=True)])), it.mean(), cpu))
     sys.stdout.flush()
