@@ -172,14 +172,16 @@ class Workload(object):
             if r is not None:
                 self.what += "; OPTION step fraction r = %g (reference: 0.9)" % r
         else:
-            m_, n_ = {"dense3": (M, N_STD), "dense2": (16, 32), "dense100": (100, 80)}[name]
+            m_, n_ = {"dense3": (M, N_STD), "dense2": (16, 32), "dense100": (100, 80), "dense200": (200, 200)}[name]
             A, b, c = problems.random_dense_arrays(m_, n_, B, seed=0, shard=rank)
             Ae, be, ce = problems.equality_arrays(A, b, c)
             lp = EqualityLP(SparseMatrix(matrix=Ae), be[:1], ce[:1], 0.0)
             solver = solver_registry["hip_dense_primal_normal"](device=dev, hsd=self.hsd, predcorr=self.predcorr, reserve_cus=reserve, **extra)
             cfg = {"dense3": "BASELINE.json configs[2]", "dense2": "BASELINE.json configs[1]",
                    "dense100": "a dense LP beyond the lane-group kernels; m = 100 is the reference's own kernel-test size, "
-                               "tests/test_ldl.py:226-238"}[name]
+                               "tests/test_ldl.py:226-238",
+                   "dense200": "a dense LP beyond the wavefront-per-LP kernel: the large-LP kernel csrc/ipm_big.hip, one LP per "
+                               "workgroup; the reference's hosts take any size, solvers/cl.py:28-83"}[name]
             self.what = ("%d random dense LPs per GPU, StandardLP (m=%d, n=%d) -> equality form N=%d, A~U[0,1) shared, "
                          "b,c~U[0.5,1.5), seed 0 (%s)" % (B, m_, n_, n_ + m_, cfg))
             if self.predcorr:
@@ -204,6 +206,7 @@ class Workload(object):
         from pycllp_amd import problems
         s, dev = self.solver, self.dev
         fname = {"dense3": "config_32x64.npz", "dense2": "config_16x32.npz", "dense100": "config_dense_100x80.npz",
+                 "dense200": "config_dense_200x200.npz",
                  "sparse5": "config_sparse_128x256.npz", "perA": "config_perA_128x256.npz"}[self.name]
         path = os.path.join(GOLDEN, fname)
         if not os.path.exists(path):
@@ -254,6 +257,8 @@ class Workload(object):
             # executed work: the slack-aware kernels (lane-group kernel and the dense-image wave kernel alike) run the Gram
             # product and the mat-vecs on the n = N - m dense columns only (the identity columns of [A | I] bypass them)
             f_exec = iters_mean * (m_ * (m_ + 1) * n_ + 8 * m_ * n_ + m_ ** 3 / 3.0 + 4 * m_ * m_ + 14 * Nn + 3 * m_)
+            # (the large-LP kernel forms both triangles of the diagonal blocks and multiplies whole 16-row blocks; still priced
+            # as the lower triangle: what it executes beyond that is overhead, not work)
         if self.predcorr:      # + one forward/back substitution (4 m^2) and A'u, A v (4 nnz resp. 4 m n) per iteration
             extra = iters_mean * (4 * m_ * m_ + (4 * (int(self.A.nnz) + m_) if self.sparse else 4 * m_ * n_))
             f_alg += extra; f_exec += extra
@@ -284,6 +289,11 @@ class Workload(object):
                                     "bytes_per_lp": b_survey, "bytes_per_lp_with_z": b_with_z}}
 
     def kernel_name(self, info):
+        if info.get("kernel") == "big":
+            return ("ipm_big_kernel (one LP per workgroup, 16 x 16 blocks of the factor in %s, Gram: %s)%s, grid %d x block %d, %d B LDS"
+                    % ("LDS" if info["lds_bytes"] > 100000 else "an L2-resident workspace", info.get("variant"),
+                       ", PYCLLP_FLAG_HSD" if self.hsd else (", PYCLLP_FLAG_PREDCORR" if self.predcorr else ""),
+                       info["grid"], info["block"], info["lds_bytes"]))
         if self.sparse or "kernel" in info:
             if info.get("kernel") == "wave":
                 return ("%s (one LP per wavefront, factor in registers, A as %s)%s, grid %d x block %d, %d B LDS"
@@ -307,7 +317,7 @@ class Workload(object):
             return cpu_reference(lambda k: sp.csr_matrix((data[k], (rows, cols)), shape=shape), self.b_std, self.c_std, seconds,
                                  "this workload, each with its own matrix")
         return cpu_reference(self.A, self.b_std, self.c_std, seconds, "this workload",
-                             chunk=256 if self.m <= 32 else 16)
+                             chunk=256 if self.m <= 32 else (16 if self.m <= 128 else 4))
 
 
 def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, cpu_from=None, predcorr=False, r=None):
@@ -345,7 +355,7 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
 
 # (workload, LPs, hsd, predcorr, step fraction or None = the reference's 0.9)
 SECONDARY = (("dense2", 4096, False, False, None), ("sparse5", 16384, False, False, None), ("sparse5", 16384, True, False, None),
-             ("perA", 16384, False, False, None), ("dense100", 16384, False, False, None),
+             ("perA", 16384, False, False, None), ("dense100", 16384, False, False, None), ("dense200", 4096, False, False, None),
              ("dense3", 65536, False, True, None), ("dense3", 65536, False, True, 0.99),
              ("sparse5", 16384, False, True, None), ("sparse5", 16384, False, True, 0.99))
 
@@ -360,7 +370,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="headline record only (no `secondary` list)")
     ap.add_argument("--hsd", action="store_true", help="time the homogeneous self-dual variant (PYCLLP_FLAG_HSD) of --workload")
     ap.add_argument("--predcorr", action="store_true", help="time the predictor-corrector option (PYCLLP_FLAG_PREDCORR) of --workload")
-    ap.add_argument("--workload", choices=("dense3", "sparse5", "perA", "dense2", "dense100"), default="dense3",
+    ap.add_argument("--workload", choices=("dense3", "sparse5", "perA", "dense2", "dense100", "dense200"), default="dense3",
                     help="dense3 (default): BASELINE.json configs[2], the headline workload; sparse5: configs[4]'s per-GPU "
                          "share (16 384 LPs, shared sparse A m=128, n=256, density 0.025) through hip_sparse_primal_normal; perA: "
                          "the same with per-problem values of A; dense2: configs[1]; dense100: 16 384 dense LPs (m=100, n=80)")
@@ -412,7 +422,7 @@ def main():
 
     B = args.batch
     if args.batch == B_PER_GPU and args.workload != "dense3":
-        B = 4096 if args.workload == "dense2" else 16384
+        B = 4096 if args.workload in ("dense2", "dense200") else 16384
     wl = Workload(args.workload, B, rank, dev, reserve=reserve, hsd=args.hsd, predcorr=args.predcorr)
     solver, bd, cd, Nn = wl.solver, wl.bd, wl.cd, wl.N
     sparse, per_a, m_, n_ = wl.sparse, wl.per_a, wl.m, wl.n

@@ -2007,7 +2007,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 #define WVARIANT(MB, NQ, DA) { MB, NQ, DA, false, do_solve<MB, NQ, DA, false>, do_solve_hsd<MB, NQ, DA, false>, do_newton<MB, NQ, DA> }
 #define WVARIANT_PA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true>, do_solve_hsd<MB, NQ, false, true>, nullptr }
 // predictor-corrector kernels of the table variants (fourth translation unit): only `solve` is meaningful
-#define WVARIANT_PC(MB, NQ) { MB, NQ, false, false, do_solve<MB, NQ, false, false, true>, nullptr, nullptr }
+#define WVARIANT_PC(MB, NQ, DA) { MB, NQ, DA, false, do_solve<MB, NQ, DA, false, true>, nullptr, nullptr }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
 const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
@@ -2050,13 +2050,25 @@ extern const int kNumWVariantsPA = sizeof(kWVariantsPA) / sizeof(kWVariantsPA[0]
 #endif
 #endif
 #if WREG_PART == 3
-#define WVARIANTS_PC { WVARIANT_PC(1, 4), WVARIANT_PC(2, 4), WVARIANT_PC(3, 4), WVARIANT_PC(4, 2), WVARIANT_PC(4, 4), WVARIANT_PC(5, 6), \
-                       WVARIANT_PC(6, 6), WVARIANT_PC(7, 6), WVARIANT_PC(8, 4), WVARIANT_PC(8, 6), WVARIANT_PC(8, 8) }
+#define WVARIANTS_PC { WVARIANT_PC(1, 4, false), WVARIANT_PC(2, 4, false), WVARIANT_PC(3, 4, false), WVARIANT_PC(4, 2, false), WVARIANT_PC(4, 4, false), \
+                       WVARIANT_PC(5, 6, false), WVARIANT_PC(6, 6, false), WVARIANT_PC(7, 6, false), WVARIANT_PC(8, 4, false), WVARIANT_PC(8, 6, false), \
+                       WVARIANT_PC(8, 8, false) }
 #ifdef __HIP_DEVICE_COMPILE__
 namespace { [[maybe_unused]] const WVariant kWVariantsPC_instantiate[] = WVARIANTS_PC; }
 #else
 extern const WVariant kWVariantsPC[] = WVARIANTS_PC;
 extern const int kNumWVariantsPC = sizeof(kWVariantsPC) / sizeof(kWVariantsPC[0]);
+#endif
+#endif
+#if WREG_PART == 4
+// predictor-corrector kernels of the dense-image variants (fifth translation unit)
+#define WVARIANTS_PCDA { WVARIANT_PC(1, 4, true), WVARIANT_PC(2, 4, true), WVARIANT_PC(3, 4, true), WVARIANT_PC(4, 2, true), WVARIANT_PC(4, 4, true), \
+                         WVARIANT_PC(5, 4, true), WVARIANT_PC(6, 4, true), WVARIANT_PC(7, 4, true), WVARIANT_PC(8, 4, true), WVARIANT_PC(8, 6, true) }
+#ifdef __HIP_DEVICE_COMPILE__
+namespace { [[maybe_unused]] const WVariant kWVariantsPCDA_instantiate[] = WVARIANTS_PCDA; }
+#else
+extern const WVariant kWVariantsPCDA[] = WVARIANTS_PCDA;
+extern const int kNumWVariantsPCDA = sizeof(kWVariantsPCDA) / sizeof(kWVariantsPCDA[0]);
 #endif
 #endif
 #if WREG_PART == 0
@@ -2312,7 +2324,7 @@ void wreg_plan_free(WregPlan* p) {
 int wreg_lds_bytes(const WregPlan* p) { return p ? p->tab.lds_bytes : 0; }
 int wreg_block_threads(const WregPlan* p) { return p ? 64 * p->tab.wpb : 0; }
 int wreg_variant(const WregPlan* p) { return p ? (p->da ? 2 : 1) : 0; }
-int wreg_has_predcorr(const WregPlan* p) { return (p && !p->da && !p->pa) ? 1 : 0; }
+int wreg_has_predcorr(const WregPlan* p) { return (p && !p->pa) ? 1 : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)
@@ -2337,9 +2349,12 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* a_batch, const d
     wsolve_fn fn = (o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve;
     if ((o.flags & PYCLLP_FLAG_PREDCORR) && !(o.flags & PYCLLP_FLAG_HSD)) {
         fn = nullptr;
-        if (!p->da && !p->pa)
-            for (int i = 0; i < kNumWVariantsPC; i++)
-                if (kWVariantsPC[i].mb == p->mb && kWVariantsPC[i].nq == p->nq) fn = kWVariantsPC[i].solve;
+        if (!p->pa) {
+            const WVariant* list = p->da ? kWVariantsPCDA : kWVariantsPC;
+            const int nlist = p->da ? kNumWVariantsPCDA : kNumWVariantsPC;
+            for (int i = 0; i < nlist; i++)
+                if (list[i].mb == p->mb && list[i].nq == p->nq) fn = list[i].solve;
+        }
         if (!fn) return hipErrorNotSupported;
     }
     return fn(p->tab, B, a_batch, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);

@@ -58,6 +58,8 @@ extern const WVariant kWVariantsPA[];
 extern const int kNumWVariantsPA;
 extern const WVariant kWVariantsPC[];      // predictor-corrector kernels of the table variants (-DWREG_PART=3)
 extern const int kNumWVariantsPC;
+extern const WVariant kWVariantsPCDA[];    // ... and of the dense-image variants (-DWREG_PART=4)
+extern const int kNumWVariantsPCDA;
 
 struct WregPlan;   // host tables + device copies for one shared constraint matrix
 
@@ -89,5 +91,5 @@ hipError_t wreg_launch_ldl_solve(int n, long B, const double* A, const double* r
 int wreg_lds_bytes(const WregPlan* p);
 int wreg_block_threads(const WregPlan* p);   // 64 x waves per workgroup
 int wreg_variant(const WregPlan* p);         // 1 = term tables, 2 = dense image
-int wreg_has_predcorr(const WregPlan* p);   // 1 when the plan's kernels have a PYCLLP_FLAG_PREDCORR variant (table plans, shared A)
+int wreg_has_predcorr(const WregPlan* p);   // 1 when the plan's kernels have a PYCLLP_FLAG_PREDCORR variant (shared A: table and dense-image plans)
 #endif

@@ -334,6 +334,18 @@ def test_large_lps_on_the_workgroup_per_lp_kernel(case, hsd):
     assert s.x.min() >= 0 and s.z.min() >= 0
 
 
+def test_large_lp_golden_objectives():
+    """tests/golden/config_dense_200x200.npz: objectives of the reference's hsd.c on 16 dense LPs of a shape only the
+    large-LP kernel covers (SURVEY 8d generator, tools/gen_golden.py large_lp_config); default plugin, 1e-8."""
+    g = golden("config_dense_200x200.npz")
+    A, b, c = problems.random_dense_arrays(200, 200, int(g["nobj"]), seed=0)
+    assert np.allclose(g["input_checksum"], [A.sum(), b.sum(), c.sum()], rtol=1e-12)
+    elp, s = solve_arrays(A, b, c)
+    assert s.launch_info()["kernel"] == "big" and (s.status == 0).all()
+    assert rel_err(s.primal_obj, g["pobj"]).max() < OBJ_TOL and rel_err(s.dual_obj, g["dobj"]).max() < OBJ_TOL
+    np.testing.assert_allclose(s.x[:8, :200], g["x"], rtol=1e-4, atol=1e-6)
+
+
 def test_large_lp_newton_step_and_statuses():
     """The stand-alone Newton step (ldl.cl:602-653 / 656-712) and the verdicts of the embedding at a size only the large-LP
     kernel covers: dy against the known-answer formula of the reference's tests/test_ldl.py:196-216; an infeasible and an
@@ -619,7 +631,7 @@ def test_predictor_corrector_options_and_large_lps():
 def test_predictor_corrector_on_the_sparse_path():
     """The same option on the wavefront-per-LP kernel: config 5's golden LPs (reference hsd.c) to 1e-8, the oracle's
     ipm_one_pc LP by LP, about half the iterations of the reference's rule on this structure (52.7 -> 25.5); a smaller
-    sparse shape; and where the option is not implemented (per-problem A, dense-image variant) it is refused, not ignored."""
+    sparse shape; the dense-image variant; and where the option is not implemented (per-problem A) it is refused, not ignored."""
     g = golden("config_sparse_128x256.npz")
     import scipy.sparse as sp
     A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(128, 256))
@@ -640,12 +652,20 @@ def test_predictor_corrector_on_the_sparse_path():
     assert (lp2.solve(s2) == 0).all()
     r2 = oracle_on(lp2, flags=128)
     assert np.abs(s2.iters.astype(int) - r2["iters"]).max() <= 1 and rel_err(s2.primal_obj, r2["pobj"]).max() < 1e-9
-    Ad, bd, cd = problems.random_dense_arrays(64, 64, 8, seed=1)              # dense-image variant of the wave kernel
+    Ad, bd, cd = problems.random_dense_arrays(100, 80, 24, seed=1)            # dense-image variant of the wave kernel
     lpd = StandardLP(SparseMatrix(matrix=Ad), bd, cd, 0.0).to_equality_form()
     sd = solver_registry["hip_dense_primal_normal"](predcorr=True, hsd=False)
     lpd.init(sd)
+    assert (lpd.solve(sd) == 0).all() and sd.launch_info()["variant"] == "dense image"
+    rd = oracle_on(lpd, flags=128)
+    assert np.abs(sd.iters.astype(int) - rd["iters"]).max() <= 1 and rel_err(sd.primal_obj, rd["pobj"]).max() < 1e-9
+    # per-problem values of A: the option is not implemented there -- refused, not ignored
+    rows, cols, data = problems.per_problem_values(A2, 8, seed=1)
+    lpp = StandardLP(SparseMatrix(rows, cols, data), b2[:8], c2[:8], 0.0).to_equality_form()
+    sp_ = solver_registry["hip_sparse_primal_normal"](predcorr=True, hsd=False)
+    lpp.init(sp_)
     with pytest.raises(NotImplementedError):
-        lpd.solve(sd)
+        lpp.solve(sp_)
 
 
 # ---- homogeneous self-dual embedding (PYCLLP_FLAG_HSD) -----------------------------------------------------

@@ -207,7 +207,10 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1:          # only the named fixtures, e.g. `gen_golden.py dense_image_config per_problem_a_config`
         for name in sys.argv[1:]:
-            globals()[name]()
+            if name == "large_lp_config":
+                dense_image_config(200, 200, 16)     # a shape only the large-LP kernel (csrc/ipm_big.hip) covers
+            else:
+                globals()[name]()
         sys.exit(0)
     textbook()
     small_problem()
@@ -217,5 +220,6 @@ if __name__ == "__main__":
     baseline_config(32, 64)
     baseline_sparse()
     dense_image_config()
+    dense_image_config(200, 200, 16)
     per_problem_a_config()
     status_cases()
