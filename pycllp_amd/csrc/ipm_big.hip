@@ -176,35 +176,58 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
     // ---- M = A diag(d) A' (d in vd) into the blocks ----
     auto gram = [&]() {
         if (T.dense) {
+            // Work unit: block row K x up to GA consecutive block columns I0 .. I0 + cnt - 1 (I0 >= K), units dealt round-robin
+            // to the waves.  Per k-step ONE scaled operand of row K feeds cnt MFMAs (independent accumulators), and the
+            // operands of step s + 1 are requested before the MFMAs of step s are issued: the first version (one block per
+            // trip, two global reads per MFMA, nothing in flight) spent 46 % of the dense kernel's time here at 1/9 of the
+            // matrix pipe's rate (profiles/r03/phase_shares_large_lp_kernel_v1.txt).
+            constexpr int GA = 8;
             const size_t step = (size_t)T.imgR * 4;
-            for (int bi = wave; bi < nblk; bi += 4) {
-                int I = (int)((sqrtf(8.0f * (float)bi + 1.0f) - 1.0f) * 0.5f);
-                while ((I + 1) * (I + 2) / 2 <= bi) I++;
-                while (I * (I + 1) / 2 > bi) I--;
-                const int K = bi - I * (I + 1) / 2;
-                double4_t acc = {0.0, 0.0, 0.0, 0.0};
-                const double* pk = T.img + (size_t)(16 * K + c16) * 4 + q;
-                const double* pi = T.img + (size_t)(16 * I + c16) * 4 + q;
-#pragma unroll 4
-                for (int s = 0; s < T.ks; s++) {
-                    const double dk = vd[4 * s + q];
-                    const double ak = pk[(size_t)s * step], ai = pi[(size_t)s * step];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ak * dk, ai, acc, 0, 0, 0);
-                }
-                if (K == I) {      // identity columns of [A | I] and the padded rows (identity rows of M)
+            int unit = 0;
+            for (int K = 0; K < MB; K++)
+                for (int I0 = K; I0 < MB; I0 += GA, unit++) {
+                    if ((unit & 3) != wave) continue;
+                    const int cnt = (MB - I0 < GA) ? MB - I0 : GA;
+                    double4_t acc[GA];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int gi = 16 * K + c16;
-                        if (4 * r + q == c16) {
-                            if (gi < m) { if (T.n_sl) acc[r] += vd[T.nd + gi]; }
-                            else acc[r] = 1.0;
+                    for (int u = 0; u < GA; u++) acc[u] = (double4_t){0.0, 0.0, 0.0, 0.0};
+                    const double* pk = T.img + (size_t)(16 * K + c16) * 4 + q;
+                    const double* pi = T.img + (size_t)(16 * I0 + c16) * 4 + q;       // block column I0 + u: + u * 64 doubles
+                    double akn = pk[0], ain[GA];
+#pragma unroll
+                    for (int u = 0; u < GA; u++) ain[u] = (u < cnt) ? pi[u * 64] : 0.0;
+                    for (int s4 = 0; s4 < T.ks; s4++) {
+                        const double ak = akn * vd[4 * s4 + q];
+                        double ai[GA];
+#pragma unroll
+                        for (int u = 0; u < GA; u++) ai[u] = ain[u];
+                        if (s4 + 1 < T.ks) {
+                            akn = pk[(size_t)(s4 + 1) * step];
+#pragma unroll
+                            for (int u = 0; u < GA; u++) if (u < cnt) ain[u] = pi[(size_t)(s4 + 1) * step + u * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < GA; u++)
+                            if (u < cnt) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ak, ai[u], acc[u], 0, 0, 0);
+                    }
+                    if (I0 == K) {      // the diagonal block: identity columns of [A | I] and the padded rows (identity rows of M)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int gi = 16 * K + c16;
+                            if (4 * r + q == c16) {
+                                if (gi < m) { if (T.n_sl) acc[0][r] += vd[T.nd + gi]; }
+                                else acc[0][r] = 1.0;
+                            }
                         }
                     }
-                }
-                double* blk = Mw + (size_t)bi * 256;
 #pragma unroll
-                for (int r = 0; r < 4; r++) blk[r * 64 + lane] = acc[r];
-            }
+                    for (int u = 0; u < GA; u++)
+                        if (u < cnt) {
+                            double* blk = Mw + (size_t)bidx(K, I0 + u) * 256;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) blk[r * 64 + lane] = acc[u][r];
+                        }
+                }
             __syncthreads();
             return;
         }
@@ -413,6 +436,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
         __syncthreads();
     };
 
+    STAMP_DECL
     for (;;) {
         // ---- next LP from the device-wide queue ----
         __syncthreads();
@@ -512,6 +536,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                     if (norms > 10.0 * norms0 && norms > PYCLLP_GROWTH_FLOOR * tol_s) { stat = PYCLLP_STATUS_DUAL_INFEASIBLE; break; }
                 }
             }
+            STAMP(0)
             // ---- d = x/z, t (plain path: c - A'y + mu/x; embedding: r1 = mu/x - z + eta sigma) ----
             double d[BNC], t[BNC];
 #pragma unroll
@@ -544,8 +569,11 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                 }
             } else if (tid < MP) um[tid] = (tid < m) ? adt - rho_i : 0.0;
             __syncthreads();
+            STAMP(1)
             gram();
+            STAMP(2)
             const bool viol = factor(beta2, hsd ? 0.0 : o.pivot_floor, hsd);
+            STAMP(3)
             if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = PYCLLP_STATUS_NUMERICAL; break; }
 
             double dx[BNC], w2[BNC], cor[BNC];
@@ -617,6 +645,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
 #pragma unroll
                 for (int k = 0; k < BNC; k++) dx[k] = (t[k] - w2[k]) * d[k];
             }
+            STAMP(4)
             // ---- x-space refinement (oracle newton_dy): e = rho - A dx; M eta = e; dx += d A'eta; dy -= eta ----
             for (;;) {
                 __syncthreads();
@@ -634,6 +663,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                 for (int k = 0; k < BNC; k++) dx[k] = fma(d[k], w2[k], dx[k]);
                 nref++;
             }
+            STAMP(5)
             const double bad = bmax((tid < MP && !isfinite(dyv[tid])) ? 1.0 : 0.0, red, tid);
             if (nwt) {
                 if (tid < m) nwt_dy[lp * m + tid] = dyv[tid];
@@ -657,6 +687,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             if (hsd) { tau = fma(theta, dtau, tau); kap = fma(theta, dkap, kap); }
             normr0 = normr; norms0 = norms;
             __syncthreads();
+            STAMP(6)
         }
         __syncthreads();
         if (nwt) continue;
@@ -674,7 +705,9 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             status[lp] = stat;
             if (iters) iters[lp] = it;
         }
+        STAMP(7)
     }
+    if (o.prof && tid == 0) { STAMP_FLUSH_BLOCK(o, blockIdx.x) }
 }
 
 template <typename T>
