@@ -1141,6 +1141,12 @@ int pycllp_hip_sparse_init(int m, int n, int nnz, const double* Adata_dev, const
     return 0;
 }
 
+// LPs the wave kernel deferred (status -1) when no guarded kernel can take them: PYCLLP_STATUS_NUMERICAL
+__global__ void deferred_to_numerical_kernel(const int* __restrict__ worklist, int* __restrict__ status) {
+    const int n = worklist[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) status[worklist[1 + i]] = PYCLLP_STATUS_NUMERICAL;
+}
+
 // which kernels of the sparse path implement the predictor-corrector step
 static bool sparse_predcorr_available(const pycllp_hip_sparse* h, bool per_problem_a, int flags) {
     if (h->big) return true;
@@ -1177,11 +1183,9 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     }
     int* worklist = nullptr;
     int grid_w = 0;
-    if (a_batch && !h->lds_with_a)
-        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values need A's arrays in LDS, and this A does not fit");
     BlockA desc = h->desc;
     int lds = h->lds;
-    if (a_batch) { desc.a_in_lds = 1; lds = h->lds_with_a; }
+    if (a_batch && h->lds_with_a) { desc.a_in_lds = 1; lds = h->lds_with_a; }
     // per-problem values: the PA plan of the wave kernel (structure tables; built on first use), else the shared-A plan
     if (a_batch && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL)) {
         std::lock_guard<std::mutex> g(h->info_mu);
@@ -1196,6 +1200,11 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     }
     WregPlan* wplan = a_batch ? h->wreg_pa : h->wreg;
     const bool use_wreg = wplan && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL);
+    // per-problem values on the block kernel need A's arrays in LDS next to the packed factor; a matrix too large for that is
+    // served by the wave kernel's PA plan alone, and an LP it defers (guard would have bitten: never observed) ends NUMERICAL
+    const bool block_can = !a_batch || h->lds_with_a != 0;
+    if (!block_can && !use_wreg)
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values of this A fit neither the wavefront-per-LP kernel's tables nor the block kernel's LDS");
     if (use_wreg) {
         // wave kernel first; whatever it defers (guard would have bitten) goes through the block kernel's guarded path
         HIP_TRY(hipMallocAsync((void**)&worklist, sizeof(int) * (size_t)(B + 1), st));
@@ -1209,13 +1218,23 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
         }
         if (ew != hipSuccess) { (void)hipFreeAsync(worklist, st); return set_err((int)ew, "ipm_wreg_kernel launch"); }
     }
+    long blocks = 0;
+    hipError_t e = hipSuccess;
+    if (!block_can) {
+        hipLaunchKernelGGL(deferred_to_numerical_kernel, dim3(64), dim3(256), 0, st, worklist, status_dev);
+        e = hipGetLastError();
+        hipError_t e2 = hipFreeAsync(worklist, st); if (e == hipSuccess) e = e2;
+        { std::lock_guard<std::mutex> g(h->info_mu); h->last_wreg = 1; h->last_plan = wplan; h->grid = grid_w; }
+        if (e != hipSuccess) return set_err((int)e, "deferred_to_numerical_kernel launch");
+        return 0;
+    }
     HIP_TRY(set_dyn_lds((const void*)ipm_block_kernel, lds));
     const long per_cu = (160 * 1024) / lds >= 4 ? 4 : ((160 * 1024) / lds >= 2 ? 2 : 1);
     const long free_cus = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
-    long blocks = free_cus * per_cu;
+    blocks = free_cus * per_cu;
     if (blocks > B) blocks = B;
     int* qhead = nullptr; unsigned slot = 0;
-    hipError_t e = h->ring.acquire(st, &qhead, &slot);
+    e = h->ring.acquire(st, &qhead, &slot);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(ipm_block_kernel, dim3((unsigned)blocks), dim3(BLK_T), lds, st, desc, B, b_dev, c_dev, x_dev,
                            y_dev, z_dev, pobj_dev, dobj_dev, status_dev, iters_dev, qhead, worklist, 0.0, nullptr, nullptr, a_batch, o);
