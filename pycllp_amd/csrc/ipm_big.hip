@@ -22,8 +22,8 @@
 //     read through L2, block substitution on wave 0.
 // Semantics = oracle/ipm_dense_ref.c (ipm_one_path / hsd_one_raw / newton_dy), like every other kernel of this library:
 // reference kernels replaced as in ipm_block.inc (pycllp/cl/primal_normal.cl:201-375, pycllp/cl/ldl.cl:314-712).
-// The Nocedal-Wright guard (ldl.cl:368) is recorded, not applied: an LP on which it would have bitten ends with
-// PYCLLP_STATUS_NUMERICAL (never observed on a positive semi-definite M; the smaller kernels defer such LPs to ipm_block_kernel).
+// The Nocedal-Wright guard (ldl.cl:368) is recorded, not applied, by the blocked factorisation; when it would have bitten
+// (rare: collapsing iterates of the embedding) M is re-formed and a column-by-column cold path applies it exactly.
 #include "big.h"
 
 namespace {
@@ -358,6 +358,45 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
         return bad > 0.0;
     };
 
+    // ---- cold path: the reference's modified LDL' with the Nocedal-Wright guard APPLIED (ldl.cl:314-378; oracle
+    //      modified_ldl_core), column by column on the blocks (re-formed by the caller), the 256 threads over the rows.  Runs only
+    //      when factor() reported that the guard would have bitten (seen on collapsing iterates of the embedding); leaves the
+    //      same representation factor() does: off-diagonal blocks Y = D L' (raw column entries), 1/D in rdv, W_K = L_KK^-1 in wl.
+    auto factor_guarded = [&](double beta2, double floor_, bool relf) {
+        auto EL = [&](int i, int k) -> double& {      // element (i, k), k <= i, of the lower triangle = U[k][i]
+            return Mw[(size_t)bidx(k >> 4, i >> 4) * 256 + boff(k & 15, i & 15)];
+        };
+        for (int j = 0; j < MP; j++) {
+            double th = 0.0;
+            for (int i = j + 1 + tid; i < MP; i += BT) th = fmax(th, fabs(EL(i, j)));
+            th = bmax(th, red, tid);
+            const double piv = EL(j, j);
+            const double aD = fmax(fmax(fabs(piv), relf ? flr[j] : floor_), th * th / beta2);      // ldl.cl:368
+            const double rD = 1.0 / aD;
+            if (tid == 0) rdv[j] = rD;
+            for (int i = j + 1 + tid; i < MP; i += BT) {
+                const double li = EL(i, j) * rD;
+                for (int k = j + 1; k <= i; k++) EL(i, k) = fma(-li, EL(k, j), EL(i, k));
+            }
+            __syncthreads();
+        }
+        // W_K = L_KK^-1 (unit lower triangular, L_ij = u_ij / D_j), column t of block K by thread (K, t)
+        for (int w0 = tid; w0 < MB * 16; w0 += BT) {
+            const int K = w0 >> 4, t = w0 & 15;
+            double wcol[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) wcol[i] = (i == t) ? 1.0 : 0.0;
+            for (int i = t + 1; i < 16; i++) {
+                double acc = 0.0;
+                for (int jj = t; jj < i; jj++) acc = fma(EL(16 * K + i, 16 * K + jj) * rdv[16 * K + jj], wcol[jj], acc);
+                wcol[i] = -acc;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) wl[K * 256 + i * 16 + t] = wcol[i];
+        }
+        __syncthreads();
+    };
+
     // ---- um <- (L D L')^-1 um: block substitution on wave 0 (forms and reductions as in ipm_wreg.hip's solve()) ----
     auto solve = [&]() {
         __syncthreads();
@@ -573,8 +612,12 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             gram();
             STAMP(2)
             const bool viol = factor(beta2, hsd ? 0.0 : o.pivot_floor, hsd);
+            if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) {
+                // the Nocedal-Wright guard would have bitten somewhere: re-form M and factor with the guard applied
+                gram();
+                factor_guarded(beta2, hsd ? 0.0 : o.pivot_floor, hsd);
+            }
             STAMP(3)
-            if (viol || (o.flags & PYCLLP_FLAG_FORCE_GUARD_PATH)) { stat = PYCLLP_STATUS_NUMERICAL; break; }
 
             double dx[BNC], w2[BNC], cor[BNC];
 #pragma unroll

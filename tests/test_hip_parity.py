@@ -334,6 +334,40 @@ def test_large_lps_on_the_workgroup_per_lp_kernel(case, hsd):
     assert s.x.min() >= 0 and s.z.min() >= 0
 
 
+@pytest.mark.parametrize("hsd", [False, True])
+def test_large_lp_guarded_cold_path(hsd):
+    """The large-LP kernel's blocked factorisation only RECORDS whether the Nocedal-Wright guard (ldl.cl:368) would have
+    bitten; when it would, M is re-formed and a column-by-column cold path applies the guard exactly (found by
+    tests/dev/fuzz_r3.py: an HSD solve at m = 154 used to end with status 3 where the oracle, whose factorisation applies the
+    guard, ends optimal).  PYCLLP_FLAG_FORCE_GUARD_PATH runs that path on every iteration: where the guard is inactive the
+    results must not change."""
+    A, b, c = problems.random_dense_arrays(150, 60, 6, seed=5)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_dense_primal_normal"](hsd=hsd, flags=4)
+    lp.init(s)
+    st = lp.solve(s)
+    assert s.launch_info()["kernel"] == "big"
+    r = oracle_on(lp, flags=32 if hsd else 0)
+    np.testing.assert_array_equal(st, r["status"])
+    assert (st == 0).all() and np.abs(s.iters.astype(int) - r["iters"]).max() <= 1
+    assert rel_err(s.primal_obj, r["pobj"]).max() < 1e-9 and rel_err(s.dual_obj, r["dobj"]).max() < 1e-9
+    # the fuzz case itself (seed 1, case 15: dense 154 x 676, two LPs): the guard bites on one of them under HSD
+    if hsd:
+        import os, sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev"))
+        from fuzz_cases import big_cases
+        case = [cs for cs in big_cases(1, 16)][15]
+        assert case[:2] == (154, 676) and case[4]
+        A2, b2, c2 = case[6], case[7], case[8]
+        lp2 = StandardLP(SparseMatrix(matrix=A2), b2, c2, 0.0).to_equality_form()
+        s2 = solver_registry["hip_dense_primal_normal"](hsd=True)
+        lp2.init(s2)
+        st2 = lp2.solve(s2)
+        r2 = oracle_on(lp2, flags=32)
+        np.testing.assert_array_equal(st2, r2["status"])
+        assert rel_err(s2.primal_obj, r2["pobj"]).max() < 1e-8
+
+
 def test_large_lp_golden_objectives():
     """tests/golden/config_dense_200x200.npz: objectives of the reference's hsd.c on 16 dense LPs of a shape only the
     large-LP kernel covers (SURVEY 8d generator, tools/gen_golden.py large_lp_config); default plugin, 1e-8."""
