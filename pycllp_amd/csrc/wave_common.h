@@ -180,6 +180,78 @@ __device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nl
 
 #include "chain_asm.inc"
 
+// ---- the same steps under an EXEC mask (ipm_group.inc, round 3) ----
+// In the lane-group kernel the mask "lanes below the pivot" and the one-hot "the pivot's lane" are compile-time constants per
+// column; taking them as EXEC masks replaces, per column, the compare + two selects that zero the multiplier of the lanes
+// on and above the pivot, the compare + two selects that pick the pivot's reciprocal, and the two multiplies + compare of the
+// guard test (now one multiply + one max into a running maximum) -- five vector instructions per column that are not FP64 work.
+// EXEC is saved and restored inside each statement, so the compiler never sees it change.  Source lanes of the broadcasts
+// are always active lanes (k > J: below the pivot).
+//   nli (in: 0 everywhere) <- -(u rD) in the lanes of the mask;  ymax <- max(ymax, |nli u|) there (= u^2 / D, the guard's
+//   test value);  Wd[k] += (src of lane k) * nli for k = J+1 .. 15.   J = -1: all sixteen entries.
+template <int J, unsigned MLO, unsigned MHI>
+__device__ __forceinline__ void chain_step_exec(double (&Wd)[16], double src, double u, double rD, double& nli, double& ymax) {
+    double t;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %19, exec\n\ts_mov_b32 exec_lo, %24\n\ts_mov_b32 exec_hi, %25\n\t"
+                 "v_mul_f64 %16, -%21, %22\n\t"
+                 "v_mul_f64 %18, %16, %21\n\t"
+                 "v_max_f64 %17, %17, |%18|\n\t"
+                 ".if 0 > %23\n\tv_fmac_f64_dpp %0, %20, %16 row_newbcast:0 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 1 > %23\n\tv_fmac_f64_dpp %1, %20, %16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 2 > %23\n\tv_fmac_f64_dpp %2, %20, %16 row_newbcast:2 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 3 > %23\n\tv_fmac_f64_dpp %3, %20, %16 row_newbcast:3 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 4 > %23\n\tv_fmac_f64_dpp %4, %20, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 5 > %23\n\tv_fmac_f64_dpp %5, %20, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 6 > %23\n\tv_fmac_f64_dpp %6, %20, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 7 > %23\n\tv_fmac_f64_dpp %7, %20, %16 row_newbcast:7 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 8 > %23\n\tv_fmac_f64_dpp %8, %20, %16 row_newbcast:8 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 9 > %23\n\tv_fmac_f64_dpp %9, %20, %16 row_newbcast:9 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 10 > %23\n\tv_fmac_f64_dpp %10, %20, %16 row_newbcast:10 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 11 > %23\n\tv_fmac_f64_dpp %11, %20, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 12 > %23\n\tv_fmac_f64_dpp %12, %20, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 13 > %23\n\tv_fmac_f64_dpp %13, %20, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 14 > %23\n\tv_fmac_f64_dpp %14, %20, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 ".if 15 > %23\n\tv_fmac_f64_dpp %15, %20, %16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n.endif\n\t"
+                 "s_mov_b64 exec, %19"
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]),
+                   "+v"(nli), "+v"(ymax), "=&v"(t), "=&s"(save)
+                 : "v"(src), "v"(u), "v"(rD), "n"(J), "n"(MLO), "n"(MHI));
+}
+// Wd[k] += (src of lane k) * nli, k = 0 .. 15, in the lanes of the mask (nli is already masked; the mask only saves the work)
+template <unsigned MLO, unsigned MHI>
+__device__ __forceinline__ void chain_all_exec(double (&Wd)[16], double src, double nli) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, %19\n\ts_mov_b32 exec_hi, %20\n\ts_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %17, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %17, %18 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %17, %18 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %17, %18 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %17, %18 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %17, %18 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %6, %17, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %7, %17, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %8, %17, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %9, %17, %18 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %10, %17, %18 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %11, %17, %18 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %12, %17, %18 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %13, %17, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %14, %17, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %15, %17, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_mov_b64 exec, %16"
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]),
+                   "=&s"(save)
+                 : "v"(src), "v"(nli), "n"(MLO), "n"(MHI));
+}
+// dst <- v in the lanes of the mask only
+template <unsigned MLO, unsigned MHI>
+__device__ __forceinline__ void mov_exec(double& dst, double v) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %3\n\ts_mov_b32 exec_hi, %4\n\tv_mov_b64 %0, %2\n\ts_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(save) : "v"(v), "n"(MLO), "n"(MHI));
+}
+
 // Unit-triangular substitution inside a 16-lane DPP row with the broadcast fused into the FMA: 15 dependent steps
 //   s -= l[k] * (s of lane k),  k = 0 .. 14   (subst15_up: forward, L)        /  k = 15 .. 1  (subst15_down: backward, L')
 // one instruction each (the compiler's form is two v_mov_b32_dpp + v_fma_f64 per step, three dependent issues); the s_nop
