@@ -1150,7 +1150,9 @@ __global__ void deferred_to_numerical_kernel(const int* __restrict__ worklist, i
 // which kernels of the sparse path implement the predictor-corrector step
 static bool sparse_predcorr_available(const pycllp_hip_sparse* h, bool per_problem_a, int flags) {
     if (h->big) return true;
-    return !per_problem_a && !(flags & PYCLLP_FLAG_BLOCK_KERNEL) && wreg_has_predcorr(h->wreg) != 0;
+    if (flags & PYCLLP_FLAG_BLOCK_KERNEL) return false;
+    // (per-problem A: the PA plan is built lazily by the first solve_batch; its kernels all have the variant)
+    return per_problem_a ? true : wreg_has_predcorr(h->wreg) != 0;
 }
 
 static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch, const double* b_dev, const double* c_dev,
@@ -1202,6 +1204,8 @@ static int sparse_solve_impl(pycllp_hip_sparse* h, long B, const double* a_batch
     const bool use_wreg = wplan && !(o.flags & PYCLLP_FLAG_BLOCK_KERNEL);
     // per-problem values on the block kernel need A's arrays in LDS next to the packed factor; a matrix too large for that is
     // served by the wave kernel's PA plan alone, and an LP it defers (guard would have bitten: never observed) ends NUMERICAL
+    if ((o.flags & PYCLLP_FLAG_PREDCORR) && !use_wreg)
+        return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve: PYCLLP_FLAG_PREDCORR is not available on the kernel that serves this LP");
     const bool block_can = !a_batch || h->lds_with_a != 0;
     if (!block_can && !use_wreg)
         return set_err(PYCLLP_E_UNSUPPORTED, "pycllp_hip_sparse_solve_batch: per-problem values of this A fit neither the wavefront-per-LP kernel's tables nor the block kernel's LDS");

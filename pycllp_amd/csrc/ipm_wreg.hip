@@ -2008,6 +2008,7 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 #define WVARIANT_PA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true>, do_solve_hsd<MB, NQ, false, true>, nullptr }
 // predictor-corrector kernels of the table variants (fourth translation unit): only `solve` is meaningful
 #define WVARIANT_PC(MB, NQ, DA) { MB, NQ, DA, false, do_solve<MB, NQ, DA, false, true>, nullptr, nullptr }
+#define WVARIANT_PCPA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true, true>, nullptr, nullptr }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
 const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
@@ -2069,6 +2070,17 @@ namespace { [[maybe_unused]] const WVariant kWVariantsPCDA_instantiate[] = WVARI
 #else
 extern const WVariant kWVariantsPCDA[] = WVARIANTS_PCDA;
 extern const int kNumWVariantsPCDA = sizeof(kWVariantsPCDA) / sizeof(kWVariantsPCDA[0]);
+#endif
+#endif
+#if WREG_PART == 5
+// predictor-corrector kernels of the per-problem-A variants (sixth translation unit)
+#define WVARIANTS_PCPA { WVARIANT_PCPA(1, 4), WVARIANT_PCPA(2, 4), WVARIANT_PCPA(3, 4), WVARIANT_PCPA(4, 2), WVARIANT_PCPA(4, 4), WVARIANT_PCPA(5, 6), \
+                         WVARIANT_PCPA(6, 6), WVARIANT_PCPA(7, 6), WVARIANT_PCPA(8, 4), WVARIANT_PCPA(8, 6), WVARIANT_PCPA(8, 8) }
+#ifdef __HIP_DEVICE_COMPILE__
+namespace { [[maybe_unused]] const WVariant kWVariantsPCPA_instantiate[] = WVARIANTS_PCPA; }
+#else
+extern const WVariant kWVariantsPCPA[] = WVARIANTS_PCPA;
+extern const int kNumWVariantsPCPA = sizeof(kWVariantsPCPA) / sizeof(kWVariantsPCPA[0]);
 #endif
 #endif
 #if WREG_PART == 0
@@ -2324,7 +2336,7 @@ void wreg_plan_free(WregPlan* p) {
 int wreg_lds_bytes(const WregPlan* p) { return p ? p->tab.lds_bytes : 0; }
 int wreg_block_threads(const WregPlan* p) { return p ? 64 * p->tab.wpb : 0; }
 int wreg_variant(const WregPlan* p) { return p ? (p->da ? 2 : 1) : 0; }
-int wreg_has_predcorr(const WregPlan* p) { return (p && !p->pa) ? 1 : 0; }
+int wreg_has_predcorr(const WregPlan* p) { return p ? 1 : 0; }
 
 static const WVariant* find_variant(const WregPlan* p) {
     for (int i = 0; i < kNumWVariants; i++)
@@ -2349,12 +2361,10 @@ hipError_t wreg_launch_solve(WregPlan* p, long B, const double* a_batch, const d
     wsolve_fn fn = (o.flags & PYCLLP_FLAG_HSD) ? v->solve_hsd : v->solve;
     if ((o.flags & PYCLLP_FLAG_PREDCORR) && !(o.flags & PYCLLP_FLAG_HSD)) {
         fn = nullptr;
-        if (!p->pa) {
-            const WVariant* list = p->da ? kWVariantsPCDA : kWVariantsPC;
-            const int nlist = p->da ? kNumWVariantsPCDA : kNumWVariantsPC;
-            for (int i = 0; i < nlist; i++)
-                if (list[i].mb == p->mb && list[i].nq == p->nq) fn = list[i].solve;
-        }
+        const WVariant* list = p->pa ? kWVariantsPCPA : (p->da ? kWVariantsPCDA : kWVariantsPC);
+        const int nlist = p->pa ? kNumWVariantsPCPA : (p->da ? kNumWVariantsPCDA : kNumWVariantsPC);
+        for (int i = 0; i < nlist; i++)
+            if (list[i].mb == p->mb && list[i].nq == p->nq) fn = list[i].solve;
         if (!fn) return hipErrorNotSupported;
     }
     return fn(p->tab, B, a_batch, b, c, x, y, z, pobj, dobj, status, iters, qhead, defer, o, (int)grid, st);

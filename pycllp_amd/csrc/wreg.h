@@ -60,6 +60,8 @@ extern const WVariant kWVariantsPC[];      // predictor-corrector kernels of the
 extern const int kNumWVariantsPC;
 extern const WVariant kWVariantsPCDA[];    // ... and of the dense-image variants (-DWREG_PART=4)
 extern const int kNumWVariantsPCDA;
+extern const WVariant kWVariantsPCPA[];    // ... and of the per-problem-A variants (-DWREG_PART=5)
+extern const int kNumWVariantsPCPA;
 
 struct WregPlan;   // host tables + device copies for one shared constraint matrix
 
@@ -91,5 +93,5 @@ hipError_t wreg_launch_ldl_solve(int n, long B, const double* A, const double* r
 int wreg_lds_bytes(const WregPlan* p);
 int wreg_block_threads(const WregPlan* p);   // 64 x waves per workgroup
 int wreg_variant(const WregPlan* p);         // 1 = term tables, 2 = dense image
-int wreg_has_predcorr(const WregPlan* p);   // 1 when the plan's kernels have a PYCLLP_FLAG_PREDCORR variant (shared A: table and dense-image plans)
+int wreg_has_predcorr(const WregPlan* p);   // 1 when the plan's kernels have a PYCLLP_FLAG_PREDCORR variant (every plan of the wave kernel)
 #endif

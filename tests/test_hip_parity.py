@@ -670,7 +670,7 @@ def test_predictor_corrector_options_and_large_lps():
 def test_predictor_corrector_on_the_sparse_path():
     """The same option on the wavefront-per-LP kernel: config 5's golden LPs (reference hsd.c) to 1e-8, the oracle's
     ipm_one_pc LP by LP, about half the iterations of the reference's rule on this structure (52.7 -> 25.5); a smaller
-    sparse shape; the dense-image variant; and where the option is not implemented (per-problem A) it is refused, not ignored."""
+    sparse shape; the dense-image and per-problem-A variants; where no kernel with the option serves the LP it is refused."""
     g = golden("config_sparse_128x256.npz")
     import scipy.sparse as sp
     A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=(128, 256))
@@ -698,13 +698,22 @@ def test_predictor_corrector_on_the_sparse_path():
     assert (lpd.solve(sd) == 0).all() and sd.launch_info()["variant"] == "dense image"
     rd = oracle_on(lpd, flags=128)
     assert np.abs(sd.iters.astype(int) - rd["iters"]).max() <= 1 and rel_err(sd.primal_obj, rd["pobj"]).max() < 1e-9
-    # per-problem values of A: the option is not implemented there -- refused, not ignored
+    # per-problem values of A: every LP against the oracle's ipm_one_pc with ITS OWN matrix
+    from oracle import port
     rows, cols, data = problems.per_problem_values(A2, 8, seed=1)
     lpp = StandardLP(SparseMatrix(rows, cols, data), b2[:8], c2[:8], 0.0).to_equality_form()
     sp_ = solver_registry["hip_sparse_primal_normal"](predcorr=True, hsd=False)
     lpp.init(sp_)
+    assert (lpp.solve(sp_) == 0).all() and sp_.launch_info()["kernel"] == "wave"
+    for k in range(8):
+        rk = port.dense_solve(lpp.A.todense(k), lpp.b[k:k + 1], lpp.c[k:k + 1], flags=128)
+        assert abs(int(sp_.iters[k]) - int(rk["iters"][0])) <= 1 and rel_err(sp_.primal_obj[k], rk["pobj"][0]) < 1e-9
+    # where no kernel with the option serves the LP (the block kernel, forced here) it is refused, not ignored
+    from pycllp_amd import _native
+    sb_ = solver_registry["hip_sparse_primal_normal"](predcorr=True, hsd=False, flags=_native.FLAG_BLOCK_KERNEL)
+    lp2.init(sb_)
     with pytest.raises(NotImplementedError):
-        lpp.solve(sp_)
+        lp2.solve(sb_)
 
 
 # ---- homogeneous self-dual embedding (PYCLLP_FLAG_HSD) -----------------------------------------------------
