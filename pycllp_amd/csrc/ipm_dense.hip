@@ -725,8 +725,12 @@ struct Variant {
 
 // ordered by cost: the first variant that covers (m, n) is used
 static const Variant kVariants[] = {
+#ifdef PYCLLP_DEV_ONLY_3296   // development builds (tools/ab_*.sh): only the headline shape, compiles in a fraction of the time
+    VARIANT(32, 96),
+#else
     VARIANT(16, 32), VARIANT(16, 48), VARIANT(16, 64), VARIANT(32, 64),
     VARIANT(32, 96), VARIANT(32, 128),
+#endif
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -735,8 +739,12 @@ struct SlackVariant { int mp, np; solve_launch_fn solve_group, solve_hsd, solve_
 #define SLACK_VARIANT(MP, NP) { MP, NP, launch_solve_group<MP, NP, true>, launch_solve_group<MP, NP, true, true>, \
                                 launch_solve_group<MP, NP, true, false, true> }
 static const SlackVariant kSlackVariants[] = {
+#ifdef PYCLLP_DEV_ONLY_3296
+    SLACK_VARIANT(32, 96),
+#else
     SLACK_VARIANT(16, 32), SLACK_VARIANT(16, 48), SLACK_VARIANT(16, 64), SLACK_VARIANT(32, 64),
     SLACK_VARIANT(32, 96), SLACK_VARIANT(32, 128),
+#endif
 };
 static const int kNumSlackVariants = sizeof(kSlackVariants) / sizeof(kSlackVariants[0]);
 

@@ -52,6 +52,10 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {
 
 // 1/a for a normal, positive a: v_rcp_f64 seed + two Newton steps (<= 1 ulp); skips the scaling/fix-up of an
 // IEEE division, which the LDL' pivots (floored at pivot_floor) never need
+// opaque copies of wave-uniform values that live in SGPRs (kernel arguments): what is derived from them is re-derived at
+// every use instead of being hoisted out of a persistent loop into long-lived VGPRs
+__device__ __forceinline__ double sopaque(double v) { asm volatile("" : "+s"(v)); return v; }
+__device__ __forceinline__ int iopaque(int v) { asm volatile("" : "+s"(v)); return v; }
 __device__ __forceinline__ double fast_rcp(double a) {
     double r = __builtin_amdgcn_rcp(a);
     r = fma(r, fma(-a, r, 1.0), r);
