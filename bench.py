@@ -356,7 +356,7 @@ def measure_secondary(name, B, dev, steps, warmup, hsd=False, cpu_seconds=4.0, c
 # (workload, LPs, hsd, predcorr, step fraction or None = the reference's 0.9)
 SECONDARY = (("dense2", 4096, False, False, None), ("sparse5", 16384, False, False, None), ("sparse5", 16384, True, False, None),
              ("perA", 16384, False, False, None), ("dense100", 16384, False, False, None), ("dense200", 4096, False, False, None),
-             ("dense3", 65536, False, True, None), ("dense3", 65536, False, True, 0.99),
+             ("dense3", 65536, True, False, None), ("dense3", 65536, False, True, None), ("dense3", 65536, False, True, 0.99),
              ("sparse5", 16384, False, True, None), ("sparse5", 16384, False, True, 0.99))
 
 

@@ -2011,8 +2011,12 @@ hipError_t do_newton(const WregTab& T, long B, const double* x, const double* z,
 #define WVARIANT_PCPA(MB, NQ) { MB, NQ, false, true, do_solve<MB, NQ, false, true, true>, nullptr, nullptr }
 // ordered by cost; the first variant of the wanted kind (tables / dense image) with 16 mb >= m and 64 nq >= n is used
 #if WREG_PART == 0
+#ifdef PYCLLP_DEV_ONLY_W86   // development builds: only the (8, 6) table variant (BASELINE config 5), compiles in a fraction of the time
+const WVariant kWVariantsTab[] = { WVARIANT(8, 6, false) };
+#else
 const WVariant kWVariantsTab[] = { WVARIANT(1, 4, false), WVARIANT(2, 4, false), WVARIANT(3, 4, false), WVARIANT(4, 2, false), WVARIANT(4, 4, false), WVARIANT(5, 6, false), WVARIANT(6, 6, false),
                                    WVARIANT(7, 6, false), WVARIANT(8, 4, false), WVARIANT(8, 6, false), WVARIANT(8, 8, false) };
+#endif
 const int kNumWVariantsTab = sizeof(kWVariantsTab) / sizeof(kWVariantsTab[0]);
 const int kNumWVariants = kNumWVariantsTab + kNumWVariantsDA + kNumWVariantsPA;
 struct VariantList {
