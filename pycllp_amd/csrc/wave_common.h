@@ -191,62 +191,87 @@ __device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nl
 // guard test (now one multiply + one max into a running maximum) -- five vector instructions per column that are not FP64 work.
 // EXEC is saved and restored inside each statement, so the compiler never sees it change.  Source lanes of the broadcasts
 // are always active lanes (k > J: below the pivot).
-//   nli (in: 0 everywhere) <- -(u rD) in the lanes of the mask;  ymax <- max(ymax, |nli u|) there (= u^2 / D, the guard's
-//   test value);  Wd[k] += (src of lane k) * nli for k = J+1 .. 15.   J = -1: all sixteen entries.
-template <int J, unsigned MLO, unsigned MHI>
-__device__ __forceinline__ void chain_step_exec(double (&Wd)[16], double src, double u, double rD, double& nli, double& ymax) {
-    double t;
-    unsigned long long save;
-    asm volatile("s_mov_b64 %19, exec\n\ts_mov_b32 exec_lo, %24\n\ts_mov_b32 exec_hi, %25\n\t"
-                 "v_mul_f64 %16, -%21, %22\n\t"
-                 "v_mul_f64 %18, %16, %21\n\t"
-                 "v_max_f64 %17, %17, |%18|\n\t"
-                 ".if 0 > %23\n\tv_fmac_f64_dpp %0, %20, %16 row_newbcast:0 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 1 > %23\n\tv_fmac_f64_dpp %1, %20, %16 row_newbcast:1 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 2 > %23\n\tv_fmac_f64_dpp %2, %20, %16 row_newbcast:2 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 3 > %23\n\tv_fmac_f64_dpp %3, %20, %16 row_newbcast:3 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 4 > %23\n\tv_fmac_f64_dpp %4, %20, %16 row_newbcast:4 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 5 > %23\n\tv_fmac_f64_dpp %5, %20, %16 row_newbcast:5 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 6 > %23\n\tv_fmac_f64_dpp %6, %20, %16 row_newbcast:6 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 7 > %23\n\tv_fmac_f64_dpp %7, %20, %16 row_newbcast:7 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 8 > %23\n\tv_fmac_f64_dpp %8, %20, %16 row_newbcast:8 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 9 > %23\n\tv_fmac_f64_dpp %9, %20, %16 row_newbcast:9 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 10 > %23\n\tv_fmac_f64_dpp %10, %20, %16 row_newbcast:10 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 11 > %23\n\tv_fmac_f64_dpp %11, %20, %16 row_newbcast:11 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 12 > %23\n\tv_fmac_f64_dpp %12, %20, %16 row_newbcast:12 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 13 > %23\n\tv_fmac_f64_dpp %13, %20, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 14 > %23\n\tv_fmac_f64_dpp %14, %20, %16 row_newbcast:14 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 ".if 15 > %23\n\tv_fmac_f64_dpp %15, %20, %16 row_newbcast:15 row_mask:0xf bank_mask:0xf\n.endif\n\t"
-                 "s_mov_b64 exec, %19"
-                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]),
-                   "+v"(nli), "+v"(ymax), "=&v"(t), "=&s"(save)
-                 : "v"(src), "v"(u), "v"(rD), "n"(J), "n"(MLO), "n"(MHI));
+//   l (in: 0 everywhere) <- u rD in the lanes of the mask, u = Wd[J] (read from the operand list: no copy);  ymax <- max(ymax,
+//   |l u|) there (= u^2 / D, the guard's test value);  Wd[k] -= (src of lane k) * l for k = J+1 .. 15 (the negation rides on the
+//   FMA's source modifier: the caller stores l itself as the column of L, where rounds 2-3 negated it twice).
+//   One function per J (the operand number of u is part of the instruction text).
+#define CHAIN_COL_FMA(K, J_) ".if " #K " > " #J_ "\n\t.if %24\n\tv_fmac_f64_dpp %" #K ", %" #J_ ", -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.else\n\t" \
+                             "v_fmac_f64_dpp %" #K ", %20, -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.endif\n.endif\n\t"
+#define DEF_CHAIN_COL(J_) \
+template <unsigned MLO, unsigned MHI, int SELF> \
+__device__ __forceinline__ void chain_col_##J_(double (&Wd)[16], double src, double rD, double& l, double& ymax) { \
+    double t; \
+    unsigned long long save; \
+    asm volatile("s_mov_b64 %19, exec\n\ts_mov_b32 exec_lo, %22\n\ts_mov_b32 exec_hi, %23\n\t" \
+                 "v_mul_f64 %16, %" #J_ ", %21\n\t" \
+                 "v_mul_f64 %18, %16, %" #J_ "\n\t" \
+                 "v_max_f64 %17, %17, |%18|\n\t" \
+                 CHAIN_COL_FMA(0, J_) \
+                 CHAIN_COL_FMA(1, J_) \
+                 CHAIN_COL_FMA(2, J_) \
+                 CHAIN_COL_FMA(3, J_) \
+                 CHAIN_COL_FMA(4, J_) \
+                 CHAIN_COL_FMA(5, J_) \
+                 CHAIN_COL_FMA(6, J_) \
+                 CHAIN_COL_FMA(7, J_) \
+                 CHAIN_COL_FMA(8, J_) \
+                 CHAIN_COL_FMA(9, J_) \
+                 CHAIN_COL_FMA(10, J_) \
+                 CHAIN_COL_FMA(11, J_) \
+                 CHAIN_COL_FMA(12, J_) \
+                 CHAIN_COL_FMA(13, J_) \
+                 CHAIN_COL_FMA(14, J_) \
+                 CHAIN_COL_FMA(15, J_) \
+                 "s_mov_b64 exec, %19" \
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]), \
+                   "+v"(l), "+v"(ymax), "=&v"(t), "=&s"(save) \
+                 : "v"(src), "v"(rD), "n"(MLO), "n"(MHI), "n"(SELF)); \
 }
-// Wd[k] += (src of lane k) * nli, k = 0 .. 15, in the lanes of the mask (nli is already masked; the mask only saves the work)
+DEF_CHAIN_COL(0) DEF_CHAIN_COL(1) DEF_CHAIN_COL(2) DEF_CHAIN_COL(3) DEF_CHAIN_COL(4) DEF_CHAIN_COL(5) DEF_CHAIN_COL(6) DEF_CHAIN_COL(7)
+DEF_CHAIN_COL(8) DEF_CHAIN_COL(9) DEF_CHAIN_COL(10) DEF_CHAIN_COL(11) DEF_CHAIN_COL(12) DEF_CHAIN_COL(13) DEF_CHAIN_COL(14) DEF_CHAIN_COL(15)
+#undef DEF_CHAIN_COL
+#undef CHAIN_COL_FMA
+// SELF = 1: the broadcast source is the column itself, Wd[J] (the pivot's DPP row is the lane's own); `src` is then not read
+template <int J, unsigned MLO, unsigned MHI, int SELF = 0>
+__device__ __forceinline__ void chain_step_exec(double (&Wd)[16], double src, double rD, double& l, double& ymax) {
+#define CHAIN_COL_CASE(J_) if constexpr (J == J_) chain_col_##J_<MLO, MHI, SELF>(Wd, src, rD, l, ymax);
+    CHAIN_COL_CASE(0) CHAIN_COL_CASE(1) CHAIN_COL_CASE(2) CHAIN_COL_CASE(3) CHAIN_COL_CASE(4) CHAIN_COL_CASE(5) CHAIN_COL_CASE(6) CHAIN_COL_CASE(7)
+    CHAIN_COL_CASE(8) CHAIN_COL_CASE(9) CHAIN_COL_CASE(10) CHAIN_COL_CASE(11) CHAIN_COL_CASE(12) CHAIN_COL_CASE(13) CHAIN_COL_CASE(14) CHAIN_COL_CASE(15)
+#undef CHAIN_COL_CASE
+}
+// Wd[k] -= (src of lane k) * l, k = 0 .. 15, in the lanes of the mask (l is already masked; the mask only saves the work)
 template <unsigned MLO, unsigned MHI>
-__device__ __forceinline__ void chain_all_exec(double (&Wd)[16], double src, double nli) {
+__device__ __forceinline__ void chain_all_exec(double (&Wd)[16], double src, double l) {
     unsigned long long save;
     asm volatile("s_mov_b64 %16, exec\n\ts_mov_b32 exec_lo, %19\n\ts_mov_b32 exec_hi, %20\n\ts_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %17, %18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, %17, %18 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %2, %17, %18 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %3, %17, %18 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %4, %17, %18 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %5, %17, %18 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %6, %17, %18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %7, %17, %18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %8, %17, %18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %9, %17, %18 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %10, %17, %18 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %11, %17, %18 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %12, %17, %18 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %13, %17, %18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %14, %17, %18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %15, %17, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %0, %17, -%18 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %17, -%18 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %17, -%18 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %17, -%18 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %17, -%18 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %17, -%18 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %6, %17, -%18 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %7, %17, -%18 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %8, %17, -%18 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %9, %17, -%18 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %10, %17, -%18 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %11, %17, -%18 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %12, %17, -%18 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %13, %17, -%18 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %14, %17, -%18 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %15, %17, -%18 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
                  "s_mov_b64 exec, %16"
                  : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]),
                    "=&s"(save)
-                 : "v"(src), "v"(nli), "n"(MLO), "n"(MHI));
+                 : "v"(src), "v"(l), "n"(MLO), "n"(MHI));
+}
+// max(|a|, b) as ONE instruction (fmax(fabs(a), b) costs a canonicalising v_max_f64 a, a first); BS: b is wave-uniform (SGPR)
+template <bool BS>
+__device__ __forceinline__ double max_abs(double a, double b) {
+    double r;
+    if constexpr (BS) asm volatile("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "s"(b));
+    else asm volatile("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 // dst <- v in the lanes of the mask only
 template <unsigned MLO, unsigned MHI>
