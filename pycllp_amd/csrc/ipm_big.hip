@@ -247,8 +247,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
     // ---- blocked LDL' of the blocks in place (see header).  RELF: the pivot floor of column j is flr[j].  Returns whether the
     //      Nocedal-Wright guard would have bitten anywhere (workgroup-uniform). ----
     auto factor = [&](double beta2, double floor_, bool relf) -> bool {
-        int viol = 0;
-        double ymax = 0.0;
+        double ymax = 0.0;       // running max of u^2 / D (pivot chains) and Y^2 / D (panels): the guard bites iff > beta^2
         for (int K = 0; K < MB; K++) {
             if (wave == 0) {
                 const double* blk = Mw + (size_t)bidx(K, K) * 256;
@@ -259,25 +258,23 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
 #pragma unroll
                 for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
                 const double myf = relf ? flr[16 * K + c16] : floor_;
-                double rdiag = 1.0, aD, rD;
+                double rdiag = 1.0, rD;
                 {
                     const double piv = bcast64<0>(Wd[0]);
-                    aD = fmax(fabs(piv), row_bcast<0>(myf));
-                    rD = fast_rcp(aD);
+                    rD = fast_rcp(fmax(fabs(piv), row_bcast<0>(myf)));
                 }
                 static_for<0, 16>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     const double u = Wd[j];
-                    const bool below = c16 > j;
-                    viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
-                    const double nli = below ? -(u * rD) : 0.0;
+                    // lanes below the pivot / the pivot's lane of every DPP row as compile-time EXEC masks (wave_common.h)
+                    constexpr unsigned m16 = ((0xFFFFu << (j + 1)) & 0xFFFFu) * 0x10001u, one16 = (1u << j) * 0x10001u;
+                    double nli;
+                    chain_head_exec<m16, one16>(u, rD, nli, ymax, rdiag);
                     Ld[j] = nli;
-                    rdiag = (c16 == j) ? rD : rdiag;
-                    asm volatile("" : "+v"(rdiag), "+v"(viol));
                     if constexpr (j < 15) {
                         double aDn, rDn;
                         chain_step_pipe_relf<j>(Wd, u, nli, 0.0, myf, aDn, rDn);
-                        aD = aDn; rD = rDn;
+                        rD = rDn;
                     }
                 });
                 if (q == 0) rdv[16 * K + c16] = rdiag;
@@ -354,7 +351,7 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
             }
             __syncthreads();
         }
-        const double bad = bmax((viol != 0 || ymax > beta2) ? 1.0 : 0.0, red, tid);
+        const double bad = bmax((ymax > beta2) ? 1.0 : 0.0, red, tid);
         return bad > 0.0;
     };
 

@@ -723,10 +723,7 @@ struct WReg {
     // Returns (wave-uniform) whether the Nocedal-Wright guard would have bitten anywhere.
     template <bool RELF>
     __device__ __forceinline__ bool factor(double beta2, double floor_ STAMP_ARGS) {
-        // guard verdict, kept as a per-lane integer that every test is folded into AT ONCE (asm pin): left as a boolean the
-        // compiler sinks the 16 + 112 compares to the end of the sweep and keeps their operands alive until then
-        int viol = 0;
-        double ymax = 0.0;
+        double ymax = 0.0, ymaxc = 0.0;     // running maxima of Y^2 / D (panels) and u^2 / D (pivot chains): the guard bites iff > beta^2
         double* tile = stage_() + TILE_OFF;
         static_for<0, MB>([&](auto Kc) {
             constexpr int K = decltype(Kc)::value;
@@ -771,28 +768,24 @@ struct WReg {
             STAMP(3)
             const double myf = RELF ? flr_()[16 * K + c16] : floor_;
             wave_lds_sync();
-            double rdiag = 1.0, aD, rD;
+            double rdiag = 1.0, rD;
             {
                 const double piv = bcast64<0>(Wd[0]);
-                aD = fmax(fabs(piv), RELF ? row_bcast<0>(myf) : floor_);
-                rD = fast_rcp(aD);
+                rD = fast_rcp(fmax(fabs(piv), RELF ? row_bcast<0>(myf) : floor_));
             }
             static_for<0, 16>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 const double u = Wd[j];
-                const bool below = c16 > j;
-                viol |= (below & (u * u > beta2 * aD)) ? 1 : 0;
-                const double nli = below ? -(u * rD) : 0.0;
+                // lanes below the pivot / the pivot's lane, in every 16-lane DPP row: compile-time EXEC masks (chain_head_exec)
+                constexpr unsigned m16 = ((0xFFFFu << (j + 1)) & 0xFFFFu) * 0x10001u, one16 = (1u << j) * 0x10001u;
+                double nli;
+                chain_head_exec<m16, one16>(u, rD, nli, ymaxc, rdiag);
                 Ld[j] = nli;
-                rdiag = (c16 == j) ? rD : rdiag;
-                // select NOW: deferred to the end of the chain (where the scheduler sinks them) the selects keep all
-                // 16 reciprocals alive and the chain spills
-                asm volatile("" : "+v"(rdiag), "+v"(viol));
                 if constexpr (j < 15) {      // Wd[k] -= l_i u_k, k > j, with the next pivot's reciprocal chain in between (chain_asm.inc)
                     double aDn, rDn;
                     if constexpr (RELF) chain_step_pipe_relf<j>(Wd, u, nli, floor_, myf, aDn, rDn);
                     else chain_step_pipe<j>(Wd, u, nli, floor_, aDn, rDn);
-                    aD = aDn; rD = rDn;
+                    rD = rDn;
                 }
             });
             if (q == 0) rdv_()[16 * K + c16] = rdiag;
@@ -856,7 +849,7 @@ struct WReg {
             __builtin_amdgcn_sched_barrier(0);   // one panel at a time: nothing of panel K+1 is hoisted above this line
         });
         wave_lds_sync();
-        return __any(viol != 0 || ymax > beta2);
+        return __any(ymax > beta2 || ymaxc > beta2);
     }
 
     // um <- (L D L')^-1 um.  Vectors of a 16-row block appear in two forms: "column form" (lane (c16, q) holds element

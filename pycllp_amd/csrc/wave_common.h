@@ -273,6 +273,26 @@ __device__ __forceinline__ double max_abs(double a, double b) {
     else asm volatile("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// Head of a pivot step of the wave kernel's 16-step chain (every 16-lane DPP row holds the same diagonal block, lane = row):
+//   nli <- -(u rD) in the lanes below the pivot (mask M16 per DPP row), 0 elsewhere;  ymax <- max(ymax, |nli u|) there (u^2 / D:
+//   the guard's test value);  rdiag <- rD in the pivot's lane (mask ONE16).
+// Five vector instructions where compares + selects on per-lane predicates took thirteen, and the multiplier no longer passes
+// through a select on its way into the trailing FMAs.  EXEC is saved and restored inside the statement.
+template <unsigned M16, unsigned ONE16>
+__device__ __forceinline__ void chain_head_exec(double u, double rD, double& nli, double& ymax, double& rdiag) {
+    double t;
+    unsigned long long save;
+    asm volatile("v_mov_b64 %0, 0\n\t"
+                 "s_mov_b64 %4, exec\n\ts_mov_b32 exec_lo, %7\n\ts_mov_b32 exec_hi, %7\n\t"
+                 "v_mul_f64 %0, -%5, %6\n\t"
+                 "v_mul_f64 %3, %0, %5\n\t"
+                 "v_max_f64 %1, %1, |%3|\n\t"
+                 "s_mov_b32 exec_lo, %8\n\ts_mov_b32 exec_hi, %8\n\t"
+                 "v_mov_b64 %2, %6\n\t"
+                 "s_mov_b64 exec, %4"
+                 : "=&v"(nli), "+v"(ymax), "+v"(rdiag), "=&v"(t), "=&s"(save)
+                 : "v"(u), "v"(rD), "n"(M16), "n"(ONE16));
+}
 // dst <- v in the lanes of the mask only
 template <unsigned MLO, unsigned MHI>
 __device__ __forceinline__ void mov_exec(double& dst, double v) {
