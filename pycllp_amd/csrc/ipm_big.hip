@@ -25,6 +25,9 @@
 // The Nocedal-Wright guard (ldl.cl:368) is recorded, not applied, by the blocked factorisation; when it would have bitten
 // (rare: collapsing iterates of the embedding) M is re-formed and a column-by-column cold path applies it exactly.
 #include "big.h"
+#ifndef PYCLLP_WINV_FUSED
+#define PYCLLP_WINV_FUSED 1     // see ipm_wreg.hip
+#endif
 
 namespace {
 
@@ -254,9 +257,12 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
 #pragma unroll
                 for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = blk[r * 64 + lane];
                 wave_lds_sync();
-                double Wd[16], Ld[16];
+                double Wd[16], Ws[4];
+                [[maybe_unused]] double Ld[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) Wd[k] = tile[c16 * 17 + k];
+#pragma unroll
+                for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
                 const double myf = relf ? flr[16 * K + c16] : floor_;
                 double rdiag = 1.0, rD;
                 {
@@ -270,22 +276,21 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                     constexpr unsigned m16 = ((0xFFFFu << (j + 1)) & 0xFFFFu) * 0x10001u, one16 = (1u << j) * 0x10001u;
                     double nli;
                     chain_head_exec<m16, one16>(u, rD, nli, ymax, rdiag);
-                    Ld[j] = nli;
                     if constexpr (j < 15) {
                         double aDn, rDn;
                         chain_step_pipe_relf<j>(Wd, u, nli, 0.0, myf, aDn, rDn);
                         rD = rDn;
+                        if constexpr (PYCLLP_WINV_FUSED) winv_step<j>(Ws, nli); else Ld[j] = nli;    // see ipm_wreg.hip
                     }
                 });
                 if (q == 0) rdv[16 * K + c16] = rdiag;
                 // W = L_KK^-1: Ws[s] = W[row c16][column 4s + q] (the A-operand layout of the panel's MFMAs); Ld holds -L
-                double Ws[4];
-#pragma unroll
-                for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
-                static_for<0, 15>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    winv_step<j>(Ws, Ld[j]);
-                });
+                if constexpr (!PYCLLP_WINV_FUSED) {
+                    static_for<0, 15>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        winv_step<j>(Ws, Ld[j]);
+                    });
+                }
 #pragma unroll
                 for (int s = 0; s < 4; s++) { wsA[s * 64 + lane] = Ws[s]; wl[K * 256 + c16 * 16 + 4 * s + q] = Ws[s]; }
             }
@@ -625,6 +630,8 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
                 // p, then q; dy = p dtau + q, dx = u dtau + v with u = d (c - A'p), v = d (r1 - A'q)
                 solve();
                 if (tid < MP) { pv[tid] = um[tid]; um[tid] = qv[tid]; }
+                __syncthreads();      // every thread reads ALL of pv below (round 3, found through a run-to-run difference of 1e-12 in
+                                      // the objectives: without this barrier waves 1-3 could read pv before wave 0 had written it)
                 double uu[BNC];
                 At_cols(pv, w2);
 #pragma unroll

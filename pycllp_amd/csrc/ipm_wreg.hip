@@ -49,13 +49,20 @@ namespace {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// A finished panel block, PARKED in eight accumulator registers.  The values are written there by inline asm with an
-// accumulator-class output, which is the one way to tell the register allocator where a long-lived, rarely read value
-// belongs: left to itself it keeps the panel results in architectural VGPRs (their next use is an MFMA B operand, which
-// may come from either file) and, out of VGPRs, spills them to scratch -- with one wavefront per SIMD every scratch
-// reload is a fully exposed memory round trip (first version of this kernel: 345 k cycles per iteration, 42 % of them in
-// the pivot chains waiting for reloads).  Reads are plain uses: the compiler copies them out (v_accvgpr_read) itself and
-// keeps track of the hazards.
+// A finished panel block.  Rounds 1-2 PARKED it in eight accumulator registers through inline asm (v_accvgpr_write with an
+// accumulator-class output): the allocator of the first versions of this kernel kept panel results in architectural VGPRs and,
+// out of those, spilled them to scratch -- with one wavefront per SIMD every reload a fully exposed memory round trip (345 k
+// cycles per iteration, 42 % of them in the pivot chains waiting for reloads).  Round 3, with the rest of the kernel no longer
+// under that pressure: the block is simply the MFMA's own result.  It stays where the matrix pipe wrote it, later MFMAs take it
+// as their B operand from the accumulator file directly, and the ~700 v_accvgpr_read / _write per iteration that moved every
+// block out of the accumulators and back are gone (PYCLLP_PARK_ASM = 1 restores the asm form): 378.5 -> 391.5 k LPs/s.
+#ifndef PYCLLP_WINV_FUSED
+#define PYCLLP_WINV_FUSED 1
+#endif
+#ifndef PYCLLP_PARK_ASM
+#define PYCLLP_PARK_ASM 0
+#endif
+#if PYCLLP_PARK_ASM
 struct PBlk { int h[8]; };
 __device__ __forceinline__ void park(PBlk& p, const double4_t& v) {
 #pragma unroll
@@ -66,6 +73,11 @@ __device__ __forceinline__ void park(PBlk& p, const double4_t& v) {
     }
 }
 __device__ __forceinline__ double unpark(const PBlk& p, int r) { return __hiloint2double(p.h[2 * r + 1], p.h[2 * r]); }
+#else
+struct PBlk { double4_t d; };
+__device__ __forceinline__ void park(PBlk& p, const double4_t& v) { p.d = v; }
+__device__ __forceinline__ double unpark(const PBlk& p, int r) { return p.d[r]; }
+#endif
 
 // stage proper: N-vector staging; during factor/solve t, x and z parked at 0, NP, 2 NP and the stride-17 tile of the current
 // diagonal block behind them
@@ -756,7 +768,10 @@ struct WReg {
             for (int r = 0; r < 4; r++) tile[(4 * r + q) * 17 + c16] = sch[r];
             wave_lds_sync();
             STAMP(2)
-            double Wd[16], Ld[16];
+            double Wd[16], Ws[4];
+            [[maybe_unused]] double Ld[16];
+#pragma unroll
+            for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
             {
                 // row c16 of the tile and of the original block (slot K, row offset c16 (c16 + 1) / 2); columns > c16: whatever
                 // follows in the slot (finite, in bounds, never used).  The two lane-dependent addresses are the same for all K.
@@ -780,25 +795,27 @@ struct WReg {
                 constexpr unsigned m16 = ((0xFFFFu << (j + 1)) & 0xFFFFu) * 0x10001u, one16 = (1u << j) * 0x10001u;
                 double nli;
                 chain_head_exec<m16, one16>(u, rD, nli, ymaxc, rdiag);
-                Ld[j] = nli;
                 if constexpr (j < 15) {      // Wd[k] -= l_i u_k, k > j, with the next pivot's reciprocal chain in between (chain_asm.inc)
                     double aDn, rDn;
                     if constexpr (RELF) chain_step_pipe_relf<j>(Wd, u, nli, floor_, myf, aDn, rDn);
                     else chain_step_pipe<j>(Wd, u, nli, floor_, aDn, rDn);
                     rD = rDn;
+                    // PYCLLP_WINV_FUSED: step j of W = L_KK^-1 (A-operand layout: Ws[s] = W[row c16][column 4s + q]; nli = -L[.][j])
+                    // rides along with the sweep instead of running as 15 steps after it: its one to four FMAs fill the tail of the
+                    // reciprocal chain that the late columns' few trailing updates leave exposed (+0.5 %, 389.4 -> 391.5 k LPs/s)
+                    if constexpr (PYCLLP_WINV_FUSED) winv_step<j>(Ws, nli); else Ld[j] = nli;
                 }
             });
             if (q == 0) rdv_()[16 * K + c16] = rdiag;
             STAMP(4)
             pin();
             // ---- W = L_KK^-1 in the A-operand layout: Ws[s] = W[row c16][column 4s + q]; packed copy to LDS (Ld holds -L) ----
-            double Ws[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) Ws[s] = (c16 == 4 * s + q) ? 1.0 : 0.0;
-            static_for<0, 15>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                winv_step<j>(Ws, Ld[j]);
-            });
+            if constexpr (!PYCLLP_WINV_FUSED) {
+                static_for<0, 15>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    winv_step<j>(Ws, Ld[j]);
+                });
+            }
             // (entries on and above the diagonal go to spare doubles of the slot: one store each, no branch; [136] and [137]
             // get the constants 1 and 0 that solve() reads for the diagonal and the upper triangle of W)
 #pragma unroll
@@ -861,34 +878,56 @@ struct WReg {
     // Forward substitution is column oriented (t_K, once known, is folded into the partial sums of all later block rows
     // and dropped), backward substitution row oriented: at most 8 + 4 doubles of vector state live.
     __device__ __forceinline__ void solve() {
-        pin();          // once: the packed-triangle offsets of w_elemT (an integer multiply each) are kept for the 16 stages
-        int woff[4];
-        w_offsets(woff);
+        pin();
+        // Everything the two sweeps read from LDS -- W_I in the transposed operand layout, 1/D in row form, the right-hand side in
+        // column form -- is fetched UP FRONT in a few batched round trips: the factor's blocks sit in the accumulator file, so the
+        // vector file is all but empty here, and a wavefront alone on its SIMD pays every LDS round trip inside the serial chain
+        // in full (rounds 1-2: nine waits per block row).  The four row sums of a block row run interleaved (row_sum4), and the
+        // partial sums p[J] are pinned per block column so that the compiler keeps the column-oriented order written here (left
+        // alone it re-associated each p[I] into one chain of up to 28 dependent FMAs in front of its use).
+        unsigned wa[4];
+        {
+            int woff[4];
+            w_offsets(woff);
+#pragma unroll
+            for (int s = 0; s < 4; s++) { wa[s] = lds_addr(wl_() + woff[s]); asm volatile("" : "+v"(wa[s])); }
+        }
+        double Wel[MB][4], rdR[MB][4], umC[MB];
+        static_for<0, MB / 4>([&](auto bc) { constexpr int b = decltype(bc)::value; lds_gather4xN<8 * WL * 4 * b, 8 * WL, 4>(wa, &Wel[4 * b][0]); });
+        if constexpr (MB % 4 >= 2) lds_gather4xN<8 * WL * (MB / 4 * 4), 8 * WL, 2>(wa, &Wel[MB / 4 * 4][0]);
+        if constexpr (MB % 2 == 1) lds_gather4xN<8 * WL * (MB - 1), 8 * WL, 1>(wa, &Wel[MB - 1][0]);
+        lds_run<0, 32, 4 * MB>(lds_addr(rdv_() + q), &rdR[0][0]);         // rdR[I][r] = 1 / D[16 I + 4 r + q]
+        lds_run<0, 128, MB>(lds_addr(um_() + c16), &umC[0]);              // umC[I] = s[16 I + c16]
         double p[MB];
 #pragma unroll
         for (int I = 0; I < MB; I++) p[I] = 0.0;
         // forward: t_I = W_I (s_I - sum_{K<I} L_IK t_K), L_IK t_K = Y_KI' (D_K^-1 t_K)
         static_for<0, MB>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;
-            double rC = um_()[16 * I + c16];
+            double rC = umC[I];
             if constexpr (I > 0) rC -= quad_sum(p[I]);
             double tR[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) tR[s] = row_sum(w_elemT<I>(s, woff) * rC);
+            for (int s = 0; s < 4; s++) tR[s] = Wel[I][s] * rC;
+            row_sum4(tR);
 #pragma unroll
             for (int s = 0; s < 4; s++) if (c16 == 0) um_()[16 * I + 4 * s + q] = tR[s];
             if constexpr (I + 1 < MB) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) tR[r] *= rdv_()[16 * I + 4 * r + q];     // D_I^-1 t_I: the resident blocks are Y = D L'
+                for (int r = 0; r < 4; r++) tR[r] *= rdR[I][r];     // D_I^-1 t_I: the resident blocks are Y = D L'
                 static_for<I + 1, MB>([&](auto Jc) {
                     constexpr int J = decltype(Jc)::value;
 #pragma unroll
                     for (int r = 0; r < 4; r++) p[J] = fma(unpark(P[G::bix(I, J)], r), tR[r], p[J]);
                 });
+#pragma unroll
+                for (int J = I + 1; J < MB; J++) asm volatile("" : "+v"(p[J]));
             }
         });
         wave_lds_sync();
         // backward: x_K = W_K' D_K^-1 (t_K - sum_{I>K} Y_KI x_I)
+        double tB[MB][4];
+        lds_run<0, 32, 4 * MB>(lds_addr(um_() + q), &tB[0][0]);           // tB[K][r] = t[16 K + 4 r + q]
         double xCL[MB];
         static_for<0, MB>([&](auto Kr) {
             constexpr int K = MB - 1 - decltype(Kr)::value;
@@ -898,12 +937,13 @@ struct WReg {
 #pragma unroll
                 for (int r = 0; r < 4; r++) pr[r] = fma(unpark(P[G::bix(K, I)], r), xCL[I], pr[r]);
             });
+            if constexpr (K < MB - 1) row_sum4(pr);
             double px = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                double v = um_()[16 * K + 4 * r + q];
-                if constexpr (K < MB - 1) v -= row_sum(pr[r]);
-                px = fma(w_elemT<K>(r, woff), v * rdv_()[16 * K + 4 * r + q], px);
+                double v = tB[K][r];
+                if constexpr (K < MB - 1) v -= pr[r];
+                px = fma(Wel[K][r], v * rdR[K][r], px);
             }
             xCL[K] = quad_sum(px);
         });

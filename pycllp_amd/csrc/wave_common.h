@@ -456,6 +456,23 @@ __device__ __forceinline__ double row_sum(double v) {
     v += dpp_d<0x140>(v);
     return v;
 }
+// four row sums at once, stage by stage: the eight DPP moves of a stage, then its four adds.  One row_sum is a chain of four
+// dependent (move, move, add) triples; four of them written one after the other run one after the other (the compiler keeps
+// them apart), which a wavefront alone on its SIMD pays in full.  Same operations and order per sum as row_sum.
+__device__ __forceinline__ void row_sum4(double (&v)[4]) {
+#define ROW_SUM4_STAGE(C)                                                                      \
+    {                                                                                          \
+        double t_[4];                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) t_[i] = dpp_d<C>(v[i]);                  \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) asm volatile("" : "+v"(t_[i]));          \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) v[i] += t_[i];                           \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) asm volatile("" : "+v"(v[i]));           \
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) asm volatile("" : "+v"(v[i]));
+    ROW_SUM4_STAGE(0xB1) ROW_SUM4_STAGE(0x4E) ROW_SUM4_STAGE(0x141) ROW_SUM4_STAGE(0x140)
+#undef ROW_SUM4_STAGE
+}
 __device__ __forceinline__ double row_max(double v) {
     v = fmax(v, dpp_d<0xB1>(v));
     v = fmax(v, dpp_d<0x4E>(v));
@@ -513,5 +530,46 @@ __device__ __forceinline__ void lds_run8(unsigned a, double* o) {
                  : "v"(a), "n"(OFF0), "n"(STRIDE) : "memory");
 }
 #undef LDS_RD_
+// o[4 b + s] = *(double*)(a[s] + OFF0 + STRIDE b), s < 4, b < NB (NB = 1, 2 or 4): the same four lane-dependent addresses in NB
+// consecutive slots of a table, one round trip
+template <int OFF0, int STRIDE, int NB>
+__device__ __forceinline__ void lds_gather4xN(const unsigned (&a)[4], double* o) {
+    static_assert(NB == 1 || NB == 2 || NB == 4, "1, 2 or 4 slots");
+    if constexpr (NB == 4) {
+        asm volatile("ds_read_b64 %0, %16 offset:%20\n\tds_read_b64 %1, %17 offset:%20\n\tds_read_b64 %2, %18 offset:%20\n\tds_read_b64 %3, %19 offset:%20\n\t"
+                     "ds_read_b64 %4, %16 offset:%20+%21\n\tds_read_b64 %5, %17 offset:%20+%21\n\tds_read_b64 %6, %18 offset:%20+%21\n\tds_read_b64 %7, %19 offset:%20+%21\n\t"
+                     "ds_read_b64 %8, %16 offset:%20+2*%21\n\tds_read_b64 %9, %17 offset:%20+2*%21\n\tds_read_b64 %10, %18 offset:%20+2*%21\n\tds_read_b64 %11, %19 offset:%20+2*%21\n\t"
+                     "ds_read_b64 %12, %16 offset:%20+3*%21\n\tds_read_b64 %13, %17 offset:%20+3*%21\n\tds_read_b64 %14, %18 offset:%20+3*%21\n\tds_read_b64 %15, %19 offset:%20+3*%21\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+                       "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(OFF0), "n"(STRIDE) : "memory");
+    } else if constexpr (NB == 2) {
+        asm volatile("ds_read_b64 %0, %8 offset:%12\n\tds_read_b64 %1, %9 offset:%12\n\tds_read_b64 %2, %10 offset:%12\n\tds_read_b64 %3, %11 offset:%12\n\t"
+                     "ds_read_b64 %4, %8 offset:%12+%13\n\tds_read_b64 %5, %9 offset:%12+%13\n\tds_read_b64 %6, %10 offset:%12+%13\n\tds_read_b64 %7, %11 offset:%12+%13\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(OFF0), "n"(STRIDE) : "memory");
+    } else {
+        asm volatile("ds_read_b64 %0, %4 offset:%8\n\tds_read_b64 %1, %5 offset:%8\n\tds_read_b64 %2, %6 offset:%8\n\tds_read_b64 %3, %7 offset:%8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(OFF0) : "memory");
+    }
+}
+// o[i] = *(double*)(a + OFF0 + STRIDE i), i < N, any N: runs of 16 / 8 and a tail of single reads
+template <int OFF0, int STRIDE, int N>
+__device__ __forceinline__ void lds_run(unsigned a, double* o) {
+    if constexpr (N >= 16) { lds_run16<OFF0, STRIDE>(a, o); lds_run<OFF0 + 16 * STRIDE, STRIDE, N - 16>(a, o + 16); }
+    else if constexpr (N >= 8) { lds_run8<OFF0, STRIDE>(a, o); lds_run<OFF0 + 8 * STRIDE, STRIDE, N - 8>(a, o + 8); }
+    else if constexpr (N >= 4) {
+        asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%5+%6\n\tds_read_b64 %2, %4 offset:%5+2*%6\n\tds_read_b64 %3, %4 offset:%5+3*%6\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a), "n"(OFF0), "n"(STRIDE) : "memory");
+        lds_run<OFF0 + 4 * STRIDE, STRIDE, N - 4>(a, o + 4);
+    } else if constexpr (N >= 1) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(o[0]) : "v"(a), "n"(OFF0) : "memory");
+        lds_run<OFF0 + STRIDE, STRIDE, N - 1>(a, o + 1);
+    }
+}
 
 #endif  // PYCLLP_WAVE_COMMON_H

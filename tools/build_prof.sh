@@ -12,5 +12,5 @@ C=pycllp_amd/csrc
 /opt/rocm/bin/hipcc $F -c -o /tmp/big_prof.o $C/ipm_big.hip &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o proflib/libpycllp_hip_prof.so /tmp/dense_prof.o /tmp/wreg_prof.o /tmp/wreg_da_prof.o \
-    $C/ipm_wreg_pa.o $C/ipm_wreg_pc.o $C/ipm_wreg_pcda.o /tmp/big_prof.o
+    $C/ipm_wreg_pa.o $C/ipm_wreg_pc.o $C/ipm_wreg_pcda.o $C/ipm_wreg_pcpa.o /tmp/big_prof.o
 ls -la proflib/
