@@ -7,6 +7,11 @@ name, commit = sys.argv[1], sys.argv[2]
 G, P = os.path.join(R, "gpurun_out", name), os.path.join(R, "profiles", name)
 os.makedirs(P, exist_ok=True)
 
+def newest(pattern):
+    """gpurun_out/ accumulates across calls: of several runs under one name, the most recent one counts"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] 
+
 def rd(f):
     d = {}
     for l in open(f):
@@ -18,10 +23,10 @@ def rd(f):
 traffic = {}
 for wl, lps, kern in (("dense3", 65536, "ipm_group_kernel<32,96,slack-aware>"), ("sparse5", 16384, "ipm_wreg_kernel<8,6>"),
                       ("perA", 16384, "ipm_wreg_kernel<8,6,per-problem A>")):
-    if not glob.glob(G + "/stats_%s/*/*kernel_stats.csv" % wl):
+    if not newest(G + "/stats_%s/*/*kernel_stats.csv" % wl):
         continue
-    shutil.copy(glob.glob(G + "/stats_%s/*/*kernel_stats.csv" % wl)[0], P + "/kernel_stats_%s.csv" % wl)
-    rows = list(csv.DictReader(open(glob.glob(G + "/stats_%s/*/*kernel_trace.csv" % wl)[0])))
+    shutil.copy(newest(G + "/stats_%s/*/*kernel_stats.csv" % wl)[0], P + "/kernel_stats_%s.csv" % wl)
+    rows = list(csv.DictReader(open(newest(G + "/stats_%s/*/*kernel_trace.csv" % wl)[0])))
     ds = []
     with open(P + "/kernel_trace_durations_%s.txt" % wl, "w") as fo:
         fo.write("# per-launch durations (ms) of the solve kernels, in launch order, from rocprofv3 --kernel-trace of\n# `python3 bench.py %s--no-cpu-baseline` "
