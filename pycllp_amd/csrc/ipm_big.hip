@@ -35,7 +35,7 @@ namespace {
 #define BIG_PAIRS_PER_TRIP 2             // block pairs of the trailing update whose reads are in flight together (per wave)
 #endif
 constexpr int BT = 256;                  // threads per workgroup
-constexpr int BNC = BIG_MAX_N / BT;      // N-vector registers per thread
+constexpr int BNC_MAX = BIG_MAX_N / BT;  // N-vector registers per thread at the largest n (the kernel is instantiated for 2, 3 and 5)
 
 struct BigTab {
     int m, n, nnz, MB, dense, m_in_lds, lds_bytes;
@@ -74,7 +74,10 @@ __host__ __device__ inline size_t big_lds_doubles(int MB, int n, bool m_in_lds) 
     return (m_in_lds ? (size_t)MB * (MB + 1) / 2 * 256 : 0) + (size_t)MB * 256 + 2 * NPv + 9 * MP + 272 + 256 + 32;
 }
 
-template <int WGPC>       // workgroups per CU the instance is compiled for (2: 256 registers per lane; 3: 168, more spills, more overlap)
+// WGPC: workgroups per CU the instance is compiled for (2: 256 registers per lane; 3: 168, more spills, more overlap).
+// BNC: N-vector registers per thread, n <= 256 BNC -- an LP with 400 columns carries two registers per N-vector, not the five
+// the size cap needs (a dozen N-vectors are live across the Newton step: 60 fewer registers at BNC = 2).
+template <int WGPC, int BNC>
 __global__ void __launch_bounds__(BT, WGPC)
 ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __restrict__ cg, double* __restrict__ xg,
                double* __restrict__ yg, double* __restrict__ zg, double* __restrict__ pobj, double* __restrict__ dobj,
@@ -488,17 +491,23 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
 
         double x[BNC], z[BNC], c[BNC];
         bool ok[BNC];
+        {
+            // (an opaque copy of the thread index: the per-thread 64-bit addresses of this LP's vectors must not be hoisted out of
+            // the LP loop as invariants -- forty registers that then sit in scratch for the whole kernel)
+            int to = tid;
+            asm volatile("" : "+v"(to));
 #pragma unroll
-        for (int k = 0; k < BNC; k++) {
-            const int j = tid + BT * k;
-            ok[k] = j < n;
-            c[k] = ok[k] ? cg[lp * n + j] : 0.0;
-            x[k] = (warm && ok[k]) ? xg[lp * n + j] : 1.0;
-            z[k] = (warm && ok[k]) ? zg[lp * n + j] : 1.0;
-        }
-        if (tid < MP) {
-            bs[tid] = (tid < m) ? bg[lp * m + tid] : 0.0;
-            ys[tid] = (tid < m) ? ((warm && yg) ? yg[lp * m + tid] : (hsd ? 0.0 : 1.0)) : 0.0;
+            for (int k = 0; k < BNC; k++) {
+                const int j = to + BT * k;
+                ok[k] = j < n;
+                c[k] = ok[k] ? cg[lp * n + j] : 0.0;
+                x[k] = (warm && ok[k]) ? xg[lp * n + j] : 1.0;
+                z[k] = (warm && ok[k]) ? zg[lp * n + j] : 1.0;
+            }
+            if (to < MP) {
+                bs[to] = (to < m) ? bg[lp * m + to] : 0.0;
+                ys[to] = (to < m) ? ((warm && yg) ? yg[lp * m + to] : (hsd ? 0.0 : 1.0)) : 0.0;
+            }
         }
         __syncthreads();
         double sb = 1.0, sc = 1.0;
@@ -740,12 +749,14 @@ ipm_big_kernel(BigTab T, long B, const double* __restrict__ bg, const double* __
         if (nwt) continue;
         // HSD: optimal (and iteration-limit) points leave the homogeneous scaling (hsd.c:266-273); certificates stay
         const double rt = (hsd && (stat == PYCLLP_STATUS_OPTIMAL || stat == PYCLLP_STATUS_ITERATION_LIMIT)) ? 1.0 / tau : 1.0;
+        int to = tid;
+        asm volatile("" : "+v"(to));
 #pragma unroll
         for (int k = 0; k < BNC; k++) {
-            const int j = tid + BT * k;
+            const int j = to + BT * k;
             if (ok[k]) { xg[lp * n + j] = x[k] * rt * sb; if (zg) zg[lp * n + j] = z[k] * rt * sc; }
         }
-        if (yg && tid < m) yg[lp * m + tid] = ys[tid] * rt * sc;
+        if (yg && to < m) yg[lp * m + to] = ys[to] * rt * sc;
         if (tid == 0) {
             if (pobj) pobj[lp] = po * rt * (sb * sc);
             if (dobj) dobj[lp] = du * rt * (sb * sc);
@@ -895,7 +906,10 @@ static hipError_t big_launch(BigPlan* p, long B, const double* b, const double* 
     // Three where the LDS allows (the instance compiled for 168 registers per lane), else two, else one.
     const long per_cu = (3 * (long)p->tab.lds_bytes <= 160 * 1024) ? 3 : ((2 * (long)p->tab.lds_bytes <= 160 * 1024) ? 2 : 1);
     cus *= per_cu;
-    auto kern = (per_cu == 3) ? ipm_big_kernel<3> : ipm_big_kernel<2>;
+    const int n_ = p->tab.n;
+    auto kern = (n_ <= 2 * BT) ? ((per_cu == 3) ? ipm_big_kernel<3, 2> : ipm_big_kernel<2, 2>)
+              : (n_ <= 3 * BT) ? ((per_cu == 3) ? ipm_big_kernel<3, 3> : ipm_big_kernel<2, 3>)
+                               : ((per_cu == 3) ? ipm_big_kernel<3, BNC_MAX> : ipm_big_kernel<2, BNC_MAX>);
     long grid = std::min(cus, B);
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
