@@ -675,11 +675,17 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     using G = GeoG<MP, NP, SL>;
     int wpb = HSD ? hsd_wpb<MP>() : PYCLLP_WPB;
     while (wpb > 1 && G::lds_bytes(wpb) > (size_t)h->max_lds) wpb--;
+    // one persistent workgroup per CU: its 8 waves already use the whole register file, so a second workgroup could not
+    // become resident whatever the LDS says
+    const long resident = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
+    // a batch too small to give every CU a full workgroup is spread over ALL CUs with fewer waves each (round 3): two waves
+    // on one SIMD share its issue port, one wave per SIMD on twice the CUs runs each LP nearly twice as fast
+    {
+        const long want = (B + (long)G::G * resident - 1) / ((long)G::G * resident);      // waves per CU that the batch fills
+        if (want < wpb) wpb = want < 1 ? 1 : (int)want;
+    }
     const long per_block = (long)wpb * G::G;
     long blocks = (B + per_block - 1) / per_block;
-    // one persistent workgroup per CU: its 8 waves (4 for the HSD kernel, compiled for 512 registers) already use the
-    // whole register file, so a second workgroup could not become resident whatever the LDS says
-    const long resident = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     const LaunchPlan p{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
