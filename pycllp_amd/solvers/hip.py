@@ -323,26 +323,49 @@ class HipDensePrimalNormalSolver(BaseSolver):
                              % (self.m, self.n, tuple(b.shape), tuple(c.shape)))
         B = int(b.shape[0])
         st, buf = self._host_staging(B), self._buffers(B, 0)
+        nchunk = max(1, min(self.PIPELINE_CHUNKS, B // self.PIPELINE_MIN_BATCH))
+        edges = [B * k // nchunk for k in range(nchunk + 1)]
+        compute = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+        outs = ("x", "y", "z", "pobj", "dobj", "status", "iters")
+
+        def stage_and_upload(lo, hi):
+            # plain memcpy on this thread: torch's CPU copy_ would wake its whole intra-op thread pool, whose
+            # spin-waiting burns a container's CPU quota and shows up as sporadic ~80 ms stalls
+            np.copyto(st["hb"][lo:hi], b[lo:hi]); np.copyto(st["hc"][lo:hi], c[lo:hi])
+            with torch.cuda.stream(st["s_in"]):
+                st["db"][lo:hi].copy_(st["b"][lo:hi], non_blocking=True)
+                st["dc"][lo:hi].copy_(st["c"][lo:hi], non_blocking=True)
+                return st["s_in"].record_event()
+
         opts = dict(self.options)
-        opts["flags"] = int(opts.get("flags", 0)) | self._extra_flags
         if warm:
             opts["flags"] = int(opts.get("flags", 0)) | _native.FLAG_WARM_START
         o = _native.default_opts(**opts)
         if o.max_iter < 1 or o.max_refine < _native.MAX_REFINE_AUTO or not (o.eps > 0):
             raise ValueError("max_iter must be >= 1, max_refine >= 0 (or -1 = auto) and eps > 0")
-        nchunk = max(1, min(self.PIPELINE_CHUNKS, B // self.PIPELINE_MIN_BATCH))
-        edges = [B * k // nchunk for k in range(nchunk + 1)]
-        compute = self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
-        outs = ("x", "y", "z", "pobj", "dobj", "status", "iters")
+        base_flags = int(o.flags)
+        # autoscale='auto' decided on the device (self._extra_flags is None): the chunks are solved WITHOUT the flag while their
+        # band tests (two row reductions each, queued behind the chunk's upload) accumulate; if some LP of the batch turns out
+        # to lie outside the band -- b or c decades away from 1: LPs that take 40-170 iterations unscaled -- the batch is solved
+        # once more with the flag from the data already on the device.  Data inside the band (the common case) keeps the
+        # full overlap of staging, upload, solve and download.
+        if self._extra_flags is None and warm:
+            # (a warm start reads the x, z, y the first pass would overwrite: decide before launching anything)
+            self._extra_flags = _native.FLAG_AUTOSCALE if autoscale_wanted(b, c) else 0
+        speculative = self._extra_flags is None
+        o.flags = base_flags | (0 if speculative else int(self._extra_flags))
+        lo_, hi_ = AUTOSCALE_BAND
+        tests = []
         with torch.cuda.device(self.device):
+            ups = []
             for lo, hi in zip(edges[:-1], edges[1:]):
-                # plain memcpy on this thread: torch's CPU copy_ would wake its whole intra-op thread pool, whose
-                # spin-waiting burns a container's CPU quota and shows up as sporadic ~80 ms stalls
-                np.copyto(st["hb"][lo:hi], b[lo:hi]); np.copyto(st["hc"][lo:hi], c[lo:hi])
-                with torch.cuda.stream(st["s_in"]):
-                    st["db"][lo:hi].copy_(st["b"][lo:hi], non_blocking=True)
-                    st["dc"][lo:hi].copy_(st["c"][lo:hi], non_blocking=True)
-                    up = st["s_in"].record_event()
+                up = stage_and_upload(lo, hi)
+                ups.append(up)
+                if speculative and hi > lo:
+                    with torch.cuda.stream(st["s_in"]):
+                        for v in (st["db"][lo:hi], st["dc"][lo:hi]):
+                            mx = v.abs().amax(dim=-1)
+                            tests.append(((mx < lo_) | (mx > hi_)).any())
                 compute.wait_event(up)
                 part = {k: buf[k][lo:hi] for k in outs}
                 self._a_row0 = lo          # (per-problem A values of the sparse solver: rows of this chunk)
@@ -353,6 +376,22 @@ class HipDensePrimalNormalSolver(BaseSolver):
                     st["s_out"].wait_event(done)
                     for k in outs:
                         st[k][lo:hi].copy_(part[k], non_blocking=True)
+            if speculative:
+                self._extra_flags = 0
+                if tests and bool(torch.stack(tests).any()):
+                    self._extra_flags = _native.FLAG_AUTOSCALE        # (the hsd='auto' re-solve of this call runs with it too)
+                    o.flags = base_flags | _native.FLAG_AUTOSCALE
+                    st["s_out"].synchronize()
+                    for lo, hi in zip(edges[:-1], edges[1:]):
+                        part = {k: buf[k][lo:hi] for k in outs}
+                        self._a_row0 = lo
+                        self._launch(hi - lo, st["db"][lo:hi], st["dc"][lo:hi], part, o)
+                        self._a_row0 = None
+                        done = compute.record_event()
+                        with torch.cuda.stream(st["s_out"]):
+                            st["s_out"].wait_event(done)
+                            for k in outs:
+                                st[k][lo:hi].copy_(part[k], non_blocking=True)
             st["s_out"].synchronize()
         return {k: st[k].numpy() for k in outs}
 
@@ -427,7 +466,14 @@ class HipDensePrimalNormalSolver(BaseSolver):
             print("Solving %d LPs with %s..." % (lp.nproblems, type(self).__name__))
         f = np.asarray(getattr(lp, "f", 0.0), dtype=np.float64)
         B = int(lp.nproblems)
-        self._extra_flags = _native.FLAG_AUTOSCALE if (self.autoscale == "auto" and autoscale_wanted(lp.b, lp.c)) else 0
+        # autoscale='auto': the band test of the whole batch.  For host arrays headed for the host pipeline it is left to the
+        # device (_solve_host: after the upload, two reductions): on 65 536 x (32 + 96) doubles the numpy version of the test
+        # took 24 ms of a 9 ms host-to-host solve.
+        host_pipeline = (not isinstance(lp.b, torch.Tensor) and not isinstance(lp.c, torch.Tensor) and not self.keep_on_device)
+        if self.autoscale == "auto" and host_pipeline:
+            self._extra_flags = None
+        else:
+            self._extra_flags = _native.FLAG_AUTOSCALE if (self.autoscale == "auto" and autoscale_wanted(lp.b, lp.c)) else 0
         try:
             return self._solve_plugin(lp, f, B, verbose)
         finally:

@@ -43,5 +43,5 @@ ts = []
 for _ in range(6):
     t = time.perf_counter(); lp5.solve(s5); ts.append(time.perf_counter() - t)
 print("sparse5 per call [ms]:", " ".join("%.1f" % (1e3 * t) for t in ts))
-print("sparse5 lp.solve() host-to-host: median %.1f ms -> %.1f k LPs/s (%d LPs of 128 x 256, device-resident: 46.3 ms)"
+print("sparse5 lp.solve() host-to-host: median %.1f ms -> %.1f k LPs/s (%d LPs of 128 x 256; device-resident: see bench.py --workload sparse5)"
       % (1e3 * np.median(ts), B5 / np.median(ts) / 1e3, B5))
