@@ -470,8 +470,8 @@ class HipDensePrimalNormalSolver(BaseSolver):
         # device (_solve_host: after the upload, two reductions): on 65 536 x (32 + 96) doubles the numpy version of the test
         # took 24 ms of a 9 ms host-to-host solve.
         host_pipeline = (not isinstance(lp.b, torch.Tensor) and not isinstance(lp.c, torch.Tensor) and not self.keep_on_device)
-        if self.autoscale == "auto" and host_pipeline:
-            self._extra_flags = None
+        if self.autoscale == "auto" and host_pipeline and B * (self.m + self.n) >= (1 << 16):
+            self._extra_flags = None       # (small batches: the numpy test costs microseconds, the device test ~8 launches)
         else:
             self._extra_flags = _native.FLAG_AUTOSCALE if (self.autoscale == "auto" and autoscale_wanted(lp.b, lp.c)) else 0
         try:
