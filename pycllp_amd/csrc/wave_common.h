@@ -265,6 +265,14 @@ __device__ __forceinline__ void chain_all_exec(double (&Wd)[16], double src, dou
                    "=&s"(save)
                  : "v"(src), "v"(l), "n"(MLO), "n"(MHI));
 }
+// one 64-bit value through LDS, as two statements: the store (no result) and, later, load + wait in ONE statement, so that the
+// compiler never sees a register whose load is still in flight.  DS operations of a wavefront execute in order.
+__device__ __forceinline__ void lds_put64(unsigned a, double v) { asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ double lds_get64(unsigned a) {
+    double r;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
 // max(|a|, b) as ONE instruction (fmax(fabs(a), b) costs a canonicalising v_max_f64 a, a first); BS: b is wave-uniform (SGPR)
 template <bool BS>
 __device__ __forceinline__ double max_abs(double a, double b) {
