@@ -678,14 +678,18 @@ static hipError_t launch_solve_group(pycllp_hip_dense* h, long B, const double* 
     // one persistent workgroup per CU: its 8 waves already use the whole register file, so a second workgroup could not
     // become resident whatever the LDS says
     const long resident = (long)h->num_cu - o.reserve_cus > 0 ? (long)h->num_cu - o.reserve_cus : 1;
-    // a batch too small to give every CU a full workgroup is spread over ALL CUs with fewer waves each (round 3): two waves
-    // on one SIMD share its issue port, one wave per SIMD on twice the CUs runs each LP nearly twice as fast
+    // a batch too small to fill every CU's eight waves (round 3).  Two waves on one SIMD share its issue port and
+    // the lane groups of a wave share its instruction stream, so: up to one wave per SIMD everywhere (4 per CU) every LP gets a
+    // wavefront of its own -- the kernel's slots are group-major, idle lane groups skip their Gram product -- then the lane
+    // groups fill, and only then does a SIMD get its second wave.
     {
-        const long want = (B + (long)G::G * resident - 1) / ((long)G::G * resident);      // waves per CU that the batch fills
-        if (want < wpb) wpb = want < 1 ? 1 : (int)want;
+        const long per_cu = (B + resident - 1) / resident;                               // LPs per CU
+        long want = (per_cu <= 4 * (long)G::G) ? (per_cu < 4 ? per_cu : 4) : (per_cu + G::G - 1) / G::G;
+        if (want < 1) want = 1;
+        if (want < wpb) wpb = (int)want;
     }
-    const long per_block = (long)wpb * G::G;
-    long blocks = (B + per_block - 1) / per_block;
+    // (workgroups: enough for one LP per wave while the batch is that small, else enough for all lane groups)
+    long blocks = (B + wpb - 1) / wpb;
     if (blocks > resident) blocks = resident;
     if (blocks < 1) blocks = 1;
     const LaunchPlan p{(int)blocks, wpb * WAVE, (int)G::lds_bytes(wpb), MP, NP};
