@@ -1399,3 +1399,48 @@ def test_every_kernel_family_is_deterministic(case, kernel, mode):
     for r in runs[1:]:
         for a, b_ in zip(runs[0], r):
             assert np.array_equal(a, b_, equal_nan=True)
+
+
+@pytest.mark.parametrize("hsd", [False, True])
+@pytest.mark.parametrize("m,n", [(32, 64), (16, 32), (7, 20)])
+def test_results_do_not_depend_on_batch_size_or_slot(m, n, hsd):
+    """An LP's x, y, z, objectives and iteration count are bit-identical whether it is solved alone, in a small batch (one LP per
+    wavefront, idle lane groups), or as part of a batch that fills every slot and is refilled from the queue: the launch plan of
+    the lane-group kernels (waves per workgroup, group-major slots) changes where an LP runs, never what is computed."""
+    B = 5000
+    A, b, c = problems.random_dense_arrays(m, n, B, seed=11 * m + n)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_dense_primal_normal"](hsd=hsd)
+    lp.init(s)
+    bd, cd = torch.as_tensor(lp.b, device="cuda"), torch.as_tensor(lp.c, device="cuda")
+    full = {k: v.clone() for k, v in s.solve_device(bd, cd).items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    assert (full["status"] == 0).all()
+    rs = np.random.RandomState(5)
+    for nb in (1, 2, 3, 64, 255, 257, 1024, 1025, 1500, 2049, 4096):
+        idx = torch.as_tensor(np.sort(rs.choice(B, size=nb, replace=False)), device="cuda")
+        part = s.solve_device(bd[idx].contiguous(), cd[idx].contiguous(), slot=1)
+        torch.cuda.synchronize()
+        for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
+            assert torch.equal(part[k][:nb], full[k][idx]), (nb, k)
+
+
+@pytest.mark.parametrize("hsd", [False, True])
+def test_sparse_results_do_not_depend_on_batch_size(hsd):
+    """The same property on the wavefront-per-LP kernel of the sparse solver (config 5's shape)."""
+    B = 600
+    A, b, c = problems.random_sparse_arrays(128, 256, B, density=0.025, seed=3)
+    lp = StandardLP(SparseMatrix(matrix=A), b, c, 0.0).to_equality_form()
+    s = solver_registry["hip_sparse_primal_normal"](hsd=hsd)
+    lp.init(s)
+    bd, cd = torch.as_tensor(lp.b, device="cuda"), torch.as_tensor(lp.c, device="cuda")
+    full = {k: v.clone() for k, v in s.solve_device(bd, cd).items() if isinstance(v, torch.Tensor)}
+    torch.cuda.synchronize()
+    assert s.launch_info()["kernel"] == "wave"
+    rs = np.random.RandomState(6)
+    for nb in (1, 5, 300):
+        idx = torch.as_tensor(np.sort(rs.choice(B, size=nb, replace=False)), device="cuda")
+        part = s.solve_device(bd[idx].contiguous(), cd[idx].contiguous(), slot=1)
+        torch.cuda.synchronize()
+        for k in ("x", "y", "z", "pobj", "dobj", "status", "iters"):
+            assert torch.equal(part[k][:nb], full[k][idx]), (nb, k)
