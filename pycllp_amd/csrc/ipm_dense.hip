@@ -737,6 +737,8 @@ struct Variant {
 static const Variant kVariants[] = {
 #ifdef PYCLLP_DEV_ONLY_3296   // development builds (tools/ab_*.sh): only the headline shape, compiles in a fraction of the time
     VARIANT(32, 96),
+#elif defined(PYCLLP_DEV_ONLY_1648)
+    VARIANT(16, 48),
 #else
     VARIANT(16, 32), VARIANT(16, 48), VARIANT(16, 64), VARIANT(32, 64),
     VARIANT(32, 96), VARIANT(32, 128),
@@ -751,6 +753,8 @@ struct SlackVariant { int mp, np; solve_launch_fn solve_group, solve_hsd, solve_
 static const SlackVariant kSlackVariants[] = {
 #ifdef PYCLLP_DEV_ONLY_3296
     SLACK_VARIANT(32, 96),
+#elif defined(PYCLLP_DEV_ONLY_1648)
+    SLACK_VARIANT(16, 48),
 #else
     SLACK_VARIANT(16, 32), SLACK_VARIANT(16, 48), SLACK_VARIANT(16, 64), SLACK_VARIANT(32, 64),
     SLACK_VARIANT(32, 96), SLACK_VARIANT(32, 128),
