@@ -195,15 +195,17 @@ __device__ __forceinline__ void chain_step(double (&Wd)[16], double u, double nl
 //   |l u|) there (= u^2 / D, the guard's test value);  Wd[k] -= (src of lane k) * l for k = J+1 .. 15 (the negation rides on the
 //   FMA's source modifier: the caller stores l itself as the column of L, where rounds 2-3 negated it twice).
 //   One function per J (the operand number of u is part of the instruction text).
-#define CHAIN_COL_FMA(K, J_) ".if " #K " > " #J_ "\n\t.if %24\n\tv_fmac_f64_dpp %" #K ", %" #J_ ", -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.else\n\t" \
-                             "v_fmac_f64_dpp %" #K ", %20, -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.endif\n.endif\n\t"
+#define CHAIN_COL_FMA(K, J_) ".if " #K " > " #J_ "\n\t.if %25\n\tv_fmac_f64_dpp %" #K ", %" #J_ ", -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.else\n\t" \
+                             "v_fmac_f64_dpp %" #K ", %21, -%16 row_newbcast:" #K " row_mask:0xf bank_mask:0xf\n.endif\n.endif\n\t"
 #define DEF_CHAIN_COL(J_) \
-template <unsigned MLO, unsigned MHI, int SELF> \
-__device__ __forceinline__ void chain_col_##J_(double (&Wd)[16], double src, double rD, double& l, double& ymax) { \
+template <unsigned MLO, unsigned MHI, int SELF, unsigned ONELO, unsigned ONEHI> \
+__device__ __forceinline__ void chain_col_##J_(double (&Wd)[16], double src, double rD, double& l, double& ymax, double& rdiag) { \
     double t; \
     unsigned long long save; \
-    asm volatile("s_mov_b64 %19, exec\n\ts_mov_b32 exec_lo, %22\n\ts_mov_b32 exec_hi, %23\n\t" \
-                 "v_mul_f64 %16, %" #J_ ", %21\n\t" \
+    asm volatile("s_mov_b64 %19, exec\n\ts_mov_b32 exec_lo, %26\n\ts_mov_b32 exec_hi, %27\n\t" \
+                 "v_mov_b64 %20, %22\n\t" \
+                 "s_mov_b32 exec_lo, %23\n\ts_mov_b32 exec_hi, %24\n\t" \
+                 "v_mul_f64 %16, %" #J_ ", %22\n\t" \
                  "v_mul_f64 %18, %16, %" #J_ "\n\t" \
                  "v_max_f64 %17, %17, |%18|\n\t" \
                  CHAIN_COL_FMA(0, J_) \
@@ -224,17 +226,18 @@ __device__ __forceinline__ void chain_col_##J_(double (&Wd)[16], double src, dou
                  CHAIN_COL_FMA(15, J_) \
                  "s_mov_b64 exec, %19" \
                  : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15]), \
-                   "+v"(l), "+v"(ymax), "=&v"(t), "=&s"(save) \
-                 : "v"(src), "v"(rD), "n"(MLO), "n"(MHI), "n"(SELF)); \
+                   "+v"(l), "+v"(ymax), "=&v"(t), "=&s"(save), "+v"(rdiag) \
+                 : "v"(src), "v"(rD), "n"(MLO), "n"(MHI), "n"(SELF), "n"(ONELO), "n"(ONEHI)); \
 }
 DEF_CHAIN_COL(0) DEF_CHAIN_COL(1) DEF_CHAIN_COL(2) DEF_CHAIN_COL(3) DEF_CHAIN_COL(4) DEF_CHAIN_COL(5) DEF_CHAIN_COL(6) DEF_CHAIN_COL(7)
 DEF_CHAIN_COL(8) DEF_CHAIN_COL(9) DEF_CHAIN_COL(10) DEF_CHAIN_COL(11) DEF_CHAIN_COL(12) DEF_CHAIN_COL(13) DEF_CHAIN_COL(14) DEF_CHAIN_COL(15)
 #undef DEF_CHAIN_COL
 #undef CHAIN_COL_FMA
 // SELF = 1: the broadcast source is the column itself, Wd[J] (the pivot's DPP row is the lane's own); `src` is then not read
-template <int J, unsigned MLO, unsigned MHI, int SELF = 0>
-__device__ __forceinline__ void chain_step_exec(double (&Wd)[16], double src, double rD, double& l, double& ymax) {
-#define CHAIN_COL_CASE(J_) if constexpr (J == J_) chain_col_##J_<MLO, MHI, SELF>(Wd, src, rD, l, ymax);
+// rdiag <- rD in the pivot's lane (mask ONELO / ONEHI) rides in the same statement: one save / restore of EXEC per column less
+template <int J, unsigned MLO, unsigned MHI, int SELF, unsigned ONELO, unsigned ONEHI>
+__device__ __forceinline__ void chain_step_exec(double (&Wd)[16], double src, double rD, double& l, double& ymax, double& rdiag) {
+#define CHAIN_COL_CASE(J_) if constexpr (J == J_) chain_col_##J_<MLO, MHI, SELF, ONELO, ONEHI>(Wd, src, rD, l, ymax, rdiag);
     CHAIN_COL_CASE(0) CHAIN_COL_CASE(1) CHAIN_COL_CASE(2) CHAIN_COL_CASE(3) CHAIN_COL_CASE(4) CHAIN_COL_CASE(5) CHAIN_COL_CASE(6) CHAIN_COL_CASE(7)
     CHAIN_COL_CASE(8) CHAIN_COL_CASE(9) CHAIN_COL_CASE(10) CHAIN_COL_CASE(11) CHAIN_COL_CASE(12) CHAIN_COL_CASE(13) CHAIN_COL_CASE(14) CHAIN_COL_CASE(15)
 #undef CHAIN_COL_CASE
