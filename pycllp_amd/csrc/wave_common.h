@@ -276,6 +276,28 @@ __device__ __forceinline__ double lds_get64(unsigned a) {
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a) : "memory");
     return r;
 }
+// Wd[k] -= (src of lane k) * l, k = 0 .. 15, in ALL lanes (no EXEC mask: for callers whose other lanes hold don't-care values)
+__device__ __forceinline__ void chain_all_neg(double (&Wd)[16], double src, double l) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %16, -%17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %16, -%17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %16, -%17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %16, -%17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %16, -%17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %5, %16, -%17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %6, %16, -%17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %7, %16, -%17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %8, %16, -%17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %9, %16, -%17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %10, %16, -%17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %11, %16, -%17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %12, %16, -%17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %13, %16, -%17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %14, %16, -%17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %15, %16, -%17 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(Wd[0]), "+v"(Wd[1]), "+v"(Wd[2]), "+v"(Wd[3]), "+v"(Wd[4]), "+v"(Wd[5]), "+v"(Wd[6]), "+v"(Wd[7]), "+v"(Wd[8]), "+v"(Wd[9]), "+v"(Wd[10]), "+v"(Wd[11]), "+v"(Wd[12]), "+v"(Wd[13]), "+v"(Wd[14]), "+v"(Wd[15])
+                 : "v"(src), "v"(l));
+}
 // max(|a|, b) as ONE instruction (fmax(fabs(a), b) costs a canonicalising v_max_f64 a, a first); BS: b is wave-uniform (SGPR)
 template <bool BS>
 __device__ __forceinline__ double max_abs(double a, double b) {
